@@ -1,0 +1,167 @@
+/*
+ * nemo_hip.h - C ABI of the MI355X (gfx950) render-and-compare pose solver.
+ *
+ * Every entry point is what a binding of the reference's hot path would call: plain pointers
+ * and sizes, no torch types.  All data pointers are DEVICE pointers owned by the caller unless
+ * a comment says "host".  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ * work is enqueued on it and the call returns without synchronising.  Return value: 0 on
+ * success, a negative NEMO_ERR_* code otherwise; nemo_last_error() then describes the failure
+ * (thread-local string).  No entry point except nemo_mesh_create / nemo_mesh_set_memory /
+ * nemo_mesh_destroy allocates or frees device memory.
+ *
+ * Conventions (PyTorch3D 0.7.1 semantics as used by the reference, see each citation):
+ *   - mesh vertices are already in render axes, i.e. after (x,y,z)->(x,z,-y)
+ *     (reference nemo/utils/mesh.py:162-170);
+ *   - a camera is (campos[3], theta) looking at the origin, up = +y, R = look_at(C) @ Rz(theta),
+ *     T = -R^T C (nemo/utils/mesh.py:222-226), screen-space pinhole with focal length `focal`
+ *     and principal point (px,py) in feature-map pixels on an H x W map (nemo/models/nemo.py:258-280);
+ *   - feature maps are float32 [*, C, H, W] contiguous (H*W is written HW below).
+ */
+#ifndef NEMO_HIP_H
+#define NEMO_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEMO_OK               0
+#define NEMO_ERR_INVALID     -1  /* bad argument (null pointer, non-positive size, ...)        */
+#define NEMO_ERR_UNSUPPORTED -2  /* size outside what the kernels are built for                */
+#define NEMO_ERR_HIP         -3  /* a HIP runtime call failed                                  */
+#define NEMO_ERR_STATE       -4  /* e.g. mesh has no vertex memory yet                         */
+
+typedef struct nemo_mesh_s* nemo_mesh_t;
+
+/* Pinhole camera shared by all poses of a call (reference: PerspectiveCameras(in_ndc=False,
+ * image_size=((H,W),), focal_length=3000/8, principal_point=((W//2,H//2),)) built at
+ * nemo/models/nemo.py:258-280 and RasterizationSettings(blur_radius=0, faces_per_pixel=1,
+ * bin_size=0) from config/models/nemo_runtime.yaml:47-54). */
+typedef struct {
+    int32_t H, W;      /* feature-map height, width                              */
+    float   focal;     /* focal length in feature-map pixels                     */
+    float   px, py;    /* principal point used when a call passes principal=NULL */
+} nemo_camera;
+
+/* Adam + ExponentialLR exactly as the reference configures them (torch.optim.Adam lr .05,
+ * betas (.4,.6), eps 1e-8; ExponentialLR gamma .2 ticking every epochs//3 steps:
+ * nemo/models/batch_solve_pose.py:306-338, config/omni_nemo_pose_3d.yaml:53-65). */
+typedef struct {
+    int32_t steps;       /* cfg.inference.epochs                                       */
+    int32_t lr_every;    /* scheduler ticks after every lr_every-th step (epochs // 3) */
+    double  lr, beta1, beta2, eps, lr_gamma;
+} nemo_adam;
+
+const char* nemo_last_error(void);
+
+/* Library / build info string (host). */
+const char* nemo_version(void);
+
+/* ---- mesh handle ------------------------------------------------------------------------
+ * Replaces the state of MeshInterpolateModuleMesh.__init__ / update_memory
+ * (nemo/models/mesh_interpolate_module.py:92-150): the mesh and the per-vertex feature memory.
+ * The handle keeps its own device copies (verts [V,3] f32, faces [F,3] i32, memory [V,C] f32
+ * and its transpose [C,V]).  face_memory[f,j,:] of the reference == memory[faces[f,j],:]
+ * (nemo/utils/mesh.py:173-174) and is never materialised. */
+int nemo_mesh_create(const float* verts, const int32_t* faces, int32_t V, int32_t F, nemo_mesh_t* out);
+int nemo_mesh_set_memory(nemo_mesh_t mesh, const float* memory /*[V,C]*/, int32_t C, void* stream);
+int nemo_mesh_destroy(nemo_mesh_t mesh);
+int nemo_mesh_info(nemo_mesh_t mesh, int32_t* V, int32_t* F, int32_t* C);
+
+/* ---- camera / projection (diagnostic + parity) -------------------------------------------
+ * campos_to_R_T (nemo/utils/mesh.py:222-226) + MeshRasterizer.transform: world -> view -> NDC.
+ * out_rt  [n,12] : R row-major (9) then T (3)                      (may be NULL)
+ * out_proj[n,V,5]: view X, Y, Z, then NDC x, y of every vertex     (may be NULL) */
+int nemo_project(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos /*[n,3]*/,
+                 const float* theta /*[n]*/, const float* principal /*[n,2] or NULL*/, int32_t n,
+                 float* out_rt, float* out_proj, void* stream);
+
+/* ---- render ------------------------------------------------------------------------------
+ * MeshInterpolateModuleMesh.forward (nemo/models/mesh_interpolate_module.py:171-217) =
+ * rasterize (nemo/utils/mesh.py:73-93, PyTorch3D naive rasteriser, nearest face per pixel) +
+ * interpolate_face_attributes (nemo/utils/mesh.py:98-148, mode='bilinear').
+ * Any output may be NULL.
+ * out_maps        [n,C,H,W] f32 : interpolated vertex features, 0 on background
+ * out_pix_to_face [n,H,W]   i32 : face index within the mesh, -1 = background
+ *                                 (the reference's packed index is i*F + this value)
+ * out_bary        [n,H,W,3] f32 : perspective-correct barycentrics, -1 on background
+ * out_zbuf        [n,H,W]   f32 : interpolated view depth, -1 on background */
+int nemo_render(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
+                const float* principal, int32_t n, float* out_maps, int32_t* out_pix_to_face,
+                float* out_bary, float* out_zbuf, void* stream);
+
+/* Backward of nemo_render's out_maps w.r.t. the camera, for callers that differentiate
+ * MeshInterpolateModule.forward themselves (what torch autograd does through PyTorch3D in the
+ * reference).  grad_maps [n,C,H,W] -> grad_campos [n,3], grad_theta [n], grad_principal [n,2]
+ * (NULL = not wanted).  The rasterisation is recomputed from the pose. */
+int nemo_render_backward(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos,
+                         const float* theta, const float* principal, int32_t n,
+                         const float* grad_maps, float* grad_campos, float* grad_theta,
+                         float* grad_principal, void* stream);
+
+/* ---- clutter score -------------------------------------------------------------------------
+ * batch_solve_pose.py:214-225: 1x1 conv of the feature map with each clutter vector, max over
+ * the K vectors.  feat [B,C,HW], clutter [K,C] -> out [B,HW]. */
+int nemo_clutter_score(const float* feat, const float* clutter, int32_t B, int32_t C, int32_t HW,
+                       int32_t K, float* out, void* stream);
+
+/* ---- pose-grid scoring ---------------------------------------------------------------------
+ * get_init_pos_rendered_dim0 (batch_solve_pose.py:128-164) with loss_fg_bg (:31-34):
+ *   obj[b,n,p] = sum_c P[n,c,p] * feat[b,c,p]
+ *   loss[b,n]  = 1 - ( mean_p max(obj, clu[b,p]) - mean_p clu[b,p] )      (clu==NULL: 1 - mean_p obj)
+ *   argmin[b]  = first n attaining min_n loss[b,n]
+ * pre [N,C,HW] (the reference's feature_pre_rendered squeezed), feat [B,C,HW], clu [B,HW].
+ * out_loss [B,N] (may be NULL), out_argmin [B] i32, out_min [B] (may be NULL).
+ * workspace: device scratch of at least nemo_grid_score_workspace(N,B,HW) bytes. */
+size_t nemo_grid_score_workspace(int32_t N, int32_t B, int32_t HW);
+int nemo_grid_score(const float* pre, const float* feat, const float* clu, int32_t N, int32_t B,
+                    int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- vertex x pixel similarity table --------------------------------------------------------
+ * table[b,v,p] = sum_c memory[v,c] * feat[b,c,p]: the reference's kpt_score_map
+ * (nemo/models/solve_pose.py:120-124) and the matmul of NeMo.fast_inference
+ * (nemo/models/nemo.py:350), computed once per image on the matrix cores so that the
+ * optimisation loop touches three scalars per covered pixel instead of 4 x C floats.
+ * feat [B,C,HW] -> table [B,V,HW] (f32). */
+int nemo_similarity_table(nemo_mesh_t mesh, const float* feat, int32_t B, int32_t HW, float* table,
+                          void* stream);
+
+/* NeMo.fast_inference (nemo/models/nemo.py:327-360) on a table: per image, over the pixel
+ * rectangle rows [r0,r1) x cols [c0,c1):  mean_p max( max_v table[b,v,p], clu[b,p] ).
+ * boxes [B,4] i32 (r0,r1,c0,c1) host or NULL for the whole map; out [B]. */
+int nemo_vertex_similarity(nemo_mesh_t mesh, const float* table, const float* clu, const int32_t* boxes_dev,
+                           int32_t B, int32_t H, int32_t W, float* out, void* stream);
+
+/* ---- pose optimisation -----------------------------------------------------------------------
+ * The Adam loop of batch_solve_pose.solve_pose (batch_solve_pose.py:306-338), all `steps`
+ * iterations inside one launch, one workgroup per hypothesis:
+ *   render at (C,theta[,principal]) -> obj = <interpolated features, feat> per pixel ->
+ *   loss_fg_bg with clutter -> backward to the pose parameters -> Adam -> LR schedule.
+ * n_hyp hypotheses; hypothesis h refines against image hyp_to_image[h] (NULL: image h).
+ * table [n_img,V,HW] from nemo_similarity_table, clu [n_img,HW].
+ * The loss of the reference is a mean over the whole batch (global_batch images x HW pixels),
+ * which sets the gradient scale seen by Adam's eps: pass the size of the batch the images
+ * belong to (a shard of a larger batch passes the larger batch's size).
+ * dof = 3: C and theta are optimised (4 scalars), principal fixed (batch_solve_pose.py:312-315)
+ * dof = 6: C, theta and principal are optimised (:308-311).
+ * out_pose [n_hyp,8]: cx, cy, cz, theta, px, py (after the last update), score (= per-image
+ *                     loss_fg_bg of the LAST forward, i.e. before the last update, as
+ *                     batch_solve_pose.py:345-359 computes it), loss of the first forward.
+ * out_loss_hist [n_hyp,steps] per-image loss at every step (may be NULL). */
+int nemo_solve(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, const float* clu,
+               const int32_t* hyp_to_image, const float* init_campos /*[n_hyp,3]*/,
+               const float* init_theta /*[n_hyp]*/, const float* init_principal /*[n_hyp,2] or NULL*/,
+               int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof, const nemo_adam* opt,
+               float* out_pose, float* out_loss_hist, void* stream);
+
+/* camera_position_to_spherical_angle (nemo/utils/mesh.py:50-56) on device:
+ * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */
+int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMO_HIP_H */

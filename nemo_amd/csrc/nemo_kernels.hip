@@ -1,0 +1,905 @@
+// HIP kernels (gfx950) and C ABI of the render-and-compare pose solver.  See include/nemo_hip.h
+// for the contract of every entry point and the reference lines each one replaces.
+//
+// Kernel inventory
+//   solve_kernel            one workgroup per pose hypothesis, all Adam steps inside the launch:
+//                           pose -> project vertices (LDS) -> rasterise faces into an LDS depth/face
+//                           key buffer (64-bit atomic min) -> per-pixel score + loss + reverse chain
+//                           -> deterministic wave/block reduction -> Adam.  No inter-workgroup traffic.
+//   render_kernel           same front end, writes fragments and the interpolated feature maps.
+//   render_backward_kernel  same front end, consumes a feature-map gradient.
+//   clutter_kernel          1x1 conv with the clutter vectors, max over vectors.
+//   grid_score_kernel       dense pose-grid scoring (partials per pixel tile) + grid_finalize_kernel.
+//   table_gemm_kernel       vertex x pixel similarity table on the f32 matrix cores (in table_gemm.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/nemo_hip.h"
+#include "geom.h"
+
+#pragma clang fp contract(off)
+
+using namespace nemo;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(NEMO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+extern "C" const char* nemo_last_error(void) { return g_err; }
+extern "C" const char* nemo_version(void) { return "nemo_hip 0.1 (gfx950, f32)"; }
+
+// ------------------------------------------------------------------------------------------
+// mesh handle
+// ------------------------------------------------------------------------------------------
+struct nemo_mesh_s {
+    int V, F, C;
+    float* verts;      // [V,3]
+    int32_t* faces;    // [F,3]
+    float* memory;     // [V,C]
+    float* memory_t;   // [C,V]
+    int device;
+};
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    int tx = threadIdx.x, ty = threadIdx.y;
+    for (int j = ty; j < 32; j += 8) {
+        int r = by + j, c = bx + tx;
+        if (r < rows && c < cols) tile[j][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = bx + j, r = by + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][j];
+    }
+}
+
+extern "C" int nemo_mesh_create(const float* verts, const int32_t* faces, int32_t V, int32_t F, nemo_mesh_t* out) {
+    if (!verts || !faces || !out || V <= 0 || F <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_create: bad argument");
+    nemo_mesh_s* m = new (std::nothrow) nemo_mesh_s();
+    if (!m) return fail(NEMO_ERR_INVALID, "out of host memory");
+    m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr;
+    HIP_TRY(hipGetDevice(&m->device));
+    HIP_TRY(hipMalloc((void**)&m->verts, sizeof(float) * 3 * V));
+    HIP_TRY(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * F));
+    HIP_TRY(hipMemcpy(m->verts, verts, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(m->faces, faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToDevice));
+    *out = m;
+    return NEMO_OK;
+}
+
+extern "C" int nemo_mesh_set_memory(nemo_mesh_t m, const float* memory, int32_t C, void* stream) {
+    if (!m || !memory || C <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_memory: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (m->C != C) {
+        if (m->memory) { HIP_TRY(hipFree(m->memory)); m->memory = nullptr; }
+        if (m->memory_t) { HIP_TRY(hipFree(m->memory_t)); m->memory_t = nullptr; }
+        HIP_TRY(hipMalloc((void**)&m->memory, sizeof(float) * (size_t)m->V * C));
+        HIP_TRY(hipMalloc((void**)&m->memory_t, sizeof(float) * (size_t)m->V * C));
+        m->C = C;
+    }
+    HIP_TRY(hipMemcpyAsync(m->memory, memory, sizeof(float) * (size_t)m->V * C, hipMemcpyDeviceToDevice, st));
+    dim3 grid((C + 31) / 32, (m->V + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, m->memory, m->memory_t, m->V, C);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" int nemo_mesh_destroy(nemo_mesh_t m) {
+    if (!m) return NEMO_OK;
+    if (m->verts) (void)hipFree(m->verts);
+    if (m->faces) (void)hipFree(m->faces);
+    if (m->memory) (void)hipFree(m->memory);
+    if (m->memory_t) (void)hipFree(m->memory_t);
+    delete m;
+    return NEMO_OK;
+}
+
+extern "C" int nemo_mesh_info(nemo_mesh_t m, int32_t* V, int32_t* F, int32_t* C) {
+    if (!m) return fail(NEMO_ERR_INVALID, "nemo_mesh_info: null mesh");
+    if (V) *V = m->V;
+    if (F) *F = m->F;
+    if (C) *C = m->C;
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave / block reductions (fixed order => bitwise reproducible)
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+
+// Sum over the 64 lanes of a wave; every lane returns the total.
+__device__ inline float wave_sum(float v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
+
+// Reduce NV values per thread over the whole block.  red: LDS scratch [nwaves][NV]; tot: LDS [NV].
+// After the call tot[k] holds the block total (visible to all threads).
+template <int NV>
+__device__ inline void block_sum(float* vals, float* red, float* tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float s = wave_sum(vals[k]);
+        if (lane == 0) red[wave * NV + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float s = 0.0f;
+        for (int w = 0; w < nw; ++w) s += red[w * NV + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS layout of the rasterising kernels
+// ------------------------------------------------------------------------------------------
+struct LdsLayout {
+    int zbuf;     // u64 [HW]
+    int vX, vY, vZ, vxn, vyn;   // f32 [V] each
+    int faces;    // i32 [F*3] (or -1: read faces from global memory)
+    int xs, ys;   // f32 [W], [H]
+    int red;      // f32 [16 waves * 16]
+    int tot;      // f32 [16]
+    int pc;       // PoseCam
+    int opt;      // OptState (solve kernel)
+    int total;
+};
+
+static inline int align16(int x) { return (x + 15) & ~15; }
+
+static LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
+    LdsLayout L;
+    int o = 0;
+    L.zbuf = o; o = align16(o + 8 * H * W);
+    L.vX = o; o = align16(o + 4 * V);
+    L.vY = o; o = align16(o + 4 * V);
+    L.vZ = o; o = align16(o + 4 * V);
+    L.vxn = o; o = align16(o + 4 * V);
+    L.vyn = o; o = align16(o + 4 * V);
+    if (faces_in_lds) { L.faces = o; o = align16(o + 12 * F); } else L.faces = -1;
+    L.xs = o; o = align16(o + 4 * W);
+    L.ys = o; o = align16(o + 4 * H);
+    L.red = o; o = align16(o + 4 * 16 * 16);
+    L.tot = o; o = align16(o + 4 * 16);
+    L.pc = o; o = align16(o + (int)sizeof(PoseCam));
+    L.opt = o; o = align16(o + 256);
+    L.total = o;
+    return L;
+}
+
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kRasterThreads = 1024;
+
+static int plan_layout(int H, int W, int V, int F, LdsLayout* L) {
+    *L = make_layout(H, W, V, F, true);
+    if (L->total > kMaxLds) *L = make_layout(H, W, V, F, false);
+    if (L->total > kMaxLds)
+        return fail(NEMO_ERR_UNSUPPORTED,
+                    "map %dx%d with %d vertices needs %d bytes of LDS per workgroup (limit %d)", H, W, V,
+                    L->total, kMaxLds);
+    return NEMO_OK;
+}
+
+struct RasterCtx {
+    const float* verts;
+    const int32_t* faces;
+    int V, F;
+    CamConst cc;
+    LdsLayout L;
+};
+
+struct Lds {
+    unsigned long long* zbuf;
+    float *vX, *vY, *vZ, *vxn, *vyn;
+    int32_t* faces;     // LDS copy or nullptr
+    float *xs, *ys, *red, *tot;
+    PoseCam* pc;
+};
+
+__device__ inline Lds carve(char* base, const LdsLayout& L) {
+    Lds s;
+    s.zbuf = (unsigned long long*)(base + L.zbuf);
+    s.vX = (float*)(base + L.vX); s.vY = (float*)(base + L.vY); s.vZ = (float*)(base + L.vZ);
+    s.vxn = (float*)(base + L.vxn); s.vyn = (float*)(base + L.vyn);
+    s.faces = L.faces >= 0 ? (int32_t*)(base + L.faces) : nullptr;
+    s.xs = (float*)(base + L.xs); s.ys = (float*)(base + L.ys);
+    s.red = (float*)(base + L.red); s.tot = (float*)(base + L.tot);
+    s.pc = (PoseCam*)(base + L.pc);
+    return s;
+}
+
+// One-time per-workgroup set-up: pixel-centre tables and the face list.
+__device__ inline void raster_prologue(const RasterCtx& rc, const Lds& s) {
+    const int H = rc.cc.H, W = rc.cc.W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) s.xs[i] = pix_to_ndc(W - 1 - i, W, H);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s.ys[i] = pix_to_ndc(H - 1 - i, H, W);
+    if (s.faces)
+        for (int i = threadIdx.x; i < rc.F * 3; i += blockDim.x) s.faces[i] = rc.faces[i];
+}
+
+__device__ inline void load_face(const RasterCtx& rc, const Lds& s, int f, int* i0, int* i1, int* i2) {
+    const int32_t* fp = s.faces ? s.faces : rc.faces;
+    *i0 = fp[3 * f + 0]; *i1 = fp[3 * f + 1]; *i2 = fp[3 * f + 2];
+}
+
+__device__ inline FaceVerts face_verts(const Lds& s, int i0, int i1, int i2) {
+    FaceVerts fv;
+    fv.x0 = s.vxn[i0]; fv.y0 = s.vyn[i0]; fv.z0 = s.vZ[i0];
+    fv.x1 = s.vxn[i1]; fv.y1 = s.vyn[i1]; fv.z1 = s.vZ[i1];
+    fv.x2 = s.vxn[i2]; fv.y2 = s.vyn[i2]; fv.z2 = s.vZ[i2];
+    return fv;
+}
+
+// Pose camera already in s.pc (and visible).  Clears the key buffer, projects every vertex and
+// rasterises every face.  On return (after the trailing barrier) s.zbuf holds, per pixel, the
+// (depth, face) key of the nearest covering face or kEmptyKey.
+__device__ inline void project_and_rasterize(const RasterCtx& rc, const Lds& s) {
+    const int HW = rc.cc.H * rc.cc.W;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) s.zbuf[p] = kEmptyKey;
+    {
+        float R[9], T[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = s.pc->R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[i] = s.pc->T[i];
+        const float bx = s.pc->bx, by = s.pc->by;
+        for (int v = threadIdx.x; v < rc.V; v += blockDim.x) {
+            float Xv[3], xn, yn;
+            project_vertex(rc.cc, R, T, bx, by, rc.verts[3 * v], rc.verts[3 * v + 1], rc.verts[3 * v + 2], Xv, &xn, &yn);
+            s.vX[v] = Xv[0]; s.vY[v] = Xv[1]; s.vZ[v] = Xv[2];
+            s.vxn[v] = xn; s.vyn[v] = yn;
+        }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < rc.F; f += blockDim.x) {
+        int i0, i1, i2;
+        load_face(rc, s, f, &i0, &i1, &i2);
+        FaceVerts fv = face_verts(s, i0, i1, i2);
+        raster_face(f, fv, rc.cc.H, rc.cc.W, s.xs, s.ys, s.zbuf);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// projection (diagnostic / parity)
+// ------------------------------------------------------------------------------------------
+__global__ void project_kernel(const float* __restrict__ verts, int V, CamConst cc, const float* __restrict__ campos,
+                               const float* __restrict__ theta, const float* __restrict__ principal, float def_px,
+                               float def_py, float* __restrict__ out_rt, float* __restrict__ out_proj) {
+    __shared__ PoseCam pc;
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float C[3] = {campos[3 * n], campos[3 * n + 1], campos[3 * n + 2]};
+        float px = principal ? principal[2 * n] : def_px, py = principal ? principal[2 * n + 1] : def_py;
+        pose_setup(cc, C, theta[n], px, py, &pc);
+        if (out_rt) {
+            for (int i = 0; i < 9; ++i) out_rt[12 * n + i] = pc.R[i];
+            for (int i = 0; i < 3; ++i) out_rt[12 * n + 9 + i] = pc.T[i];
+        }
+    }
+    __syncthreads();
+    if (!out_proj) return;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float Xv[3], xn, yn;
+        project_vertex(cc, pc.R, pc.T, pc.bx, pc.by, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2], Xv, &xn, &yn);
+        float* o = out_proj + ((size_t)n * V + v) * 5;
+        o[0] = Xv[0]; o[1] = Xv[1]; o[2] = Xv[2]; o[3] = xn; o[4] = yn;
+    }
+}
+
+static int check_cam(const nemo_camera* cam) {
+    if (!cam || cam->H <= 0 || cam->W <= 0 || !(cam->focal > 0.0f)) return fail(NEMO_ERR_INVALID, "bad camera");
+    return NEMO_OK;
+}
+
+extern "C" int nemo_project(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                            const float* principal, int32_t n, float* out_rt, float* out_proj, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!m || !campos || !theta || n < 0) return fail(NEMO_ERR_INVALID, "nemo_project: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    CamConst cc = make_cam_const(cam->H, cam->W, cam->focal);
+    hipLaunchKernelGGL(project_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, m->verts, m->V, cc, campos, theta,
+                       principal, cam->px, cam->py, out_rt, out_proj);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// render
+// ------------------------------------------------------------------------------------------
+struct RenderArgs {
+    RasterCtx rc;
+    const float* memory_t;   // [C,V]
+    int C;
+    const float* campos; const float* theta; const float* principal;
+    float def_px, def_py;
+    float* out_maps; int32_t* out_p2f; float* out_bary; float* out_zbuf;
+};
+
+__global__ __launch_bounds__(kRasterThreads) void render_kernel(RenderArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds s = carve(smem, a.rc.L);
+    const int n = blockIdx.x;
+    const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
+    raster_prologue(a.rc, s);
+    if (threadIdx.x == 0) {
+        float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
+        float px = a.principal ? a.principal[2 * n] : a.def_px, py = a.principal ? a.principal[2 * n + 1] : a.def_py;
+        pose_setup(a.rc.cc, C, a.theta[n], px, py, s.pc);
+    }
+    __syncthreads();
+    project_and_rasterize(a.rc, s);
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        unsigned long long key = s.zbuf[p];
+        int f = -1;
+        float b[3] = {-1.0f, -1.0f, -1.0f}, pz = -1.0f;
+        int i0 = 0, i1 = 0, i2 = 0;
+        if (key != kEmptyKey) {
+            f = (int)(key & 0xFFFFFFFFull);
+            load_face(a.rc, s, f, &i0, &i1, &i2);
+            FaceVerts fv = face_verts(s, i0, i1, i2);
+            int yi = p / W, xi = p - yi * W;
+            face_eval(fv, s.xs[xi], s.ys[yi], b, &pz);
+        }
+        if (a.out_p2f) a.out_p2f[(size_t)n * HW + p] = f;
+        if (a.out_zbuf) a.out_zbuf[(size_t)n * HW + p] = pz;
+        if (a.out_bary) {
+            float* ob = a.out_bary + ((size_t)n * HW + p) * 3;
+            ob[0] = b[0]; ob[1] = b[1]; ob[2] = b[2];
+        }
+        if (a.out_maps) {
+            float* om = a.out_maps + (size_t)n * a.C * HW + p;
+            if (f >= 0) {
+                for (int c = 0; c < a.C; ++c) {
+                    const float* mt = a.memory_t + (size_t)c * V;
+                    om[(size_t)c * HW] = (b[0] * mt[i0] + b[1] * mt[i1]) + b[2] * mt[i2];
+                }
+            } else {
+                for (int c = 0; c < a.C; ++c) om[(size_t)c * HW] = 0.0f;
+            }
+        }
+    }
+}
+
+template <typename K>
+static int set_lds_limit(K kernel, int bytes) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return NEMO_OK;
+}
+
+extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                           const float* principal, int32_t n, float* out_maps, int32_t* out_p2f, float* out_bary,
+                           float* out_zbuf, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!m || !campos || !theta || n < 0) return fail(NEMO_ERR_INVALID, "nemo_render: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    if (out_maps && !m->memory_t) return fail(NEMO_ERR_STATE, "nemo_render: mesh has no vertex memory (call nemo_mesh_set_memory)");
+    RenderArgs a;
+    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, &a.rc.L);
+    if (rcode) return rcode;
+    a.memory_t = m->memory_t; a.C = m->C;
+    a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
+    a.out_maps = out_maps; a.out_p2f = out_p2f; a.out_bary = out_bary; a.out_zbuf = out_zbuf;
+    if (set_lds_limit(render_kernel, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(render_kernel, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// render backward
+// ------------------------------------------------------------------------------------------
+struct RenderBwdArgs {
+    RasterCtx rc;
+    const float* memory_t; int C;
+    const float* campos; const float* theta; const float* principal;
+    float def_px, def_py;
+    const float* grad_maps;
+    float* g_campos; float* g_theta; float* g_principal;
+};
+
+__global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds s = carve(smem, a.rc.L);
+    const int n = blockIdx.x;
+    const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
+    raster_prologue(a.rc, s);
+    PoseCam pc_local;
+    if (threadIdx.x == 0) {
+        float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
+        float px = a.principal ? a.principal[2 * n] : a.def_px, py = a.principal ? a.principal[2 * n + 1] : a.def_py;
+        pose_setup(a.rc.cc, C, a.theta[n], px, py, &pc_local);
+        *s.pc = pc_local;
+    }
+    __syncthreads();
+    project_and_rasterize(a.rc, s);
+    PixelGrad acc;
+    for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
+    acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        unsigned long long key = s.zbuf[p];
+        if (key == kEmptyKey) continue;
+        int f = (int)(key & 0xFFFFFFFFull), i0, i1, i2;
+        load_face(a.rc, s, f, &i0, &i1, &i2);
+        FaceVerts fv = face_verts(s, i0, i1, i2);
+        int yi = p / W, xi = p - yi * W;
+        float gb[3] = {0.f, 0.f, 0.f};
+        const float* gm = a.grad_maps + (size_t)n * a.C * HW + p;
+        for (int c = 0; c < a.C; ++c) {
+            float g = gm[(size_t)c * HW];
+            const float* mt = a.memory_t + (size_t)c * V;
+            gb[0] += g * mt[i0]; gb[1] += g * mt[i1]; gb[2] += g * mt[i2];
+        }
+        float X0[3] = {s.vX[i0], s.vY[i0], s.vZ[i0]}, X1[3] = {s.vX[i1], s.vY[i1], s.vZ[i1]},
+              X2[3] = {s.vX[i2], s.vY[i2], s.vZ[i2]};
+        pixel_backward(a.rc.cc, fv, X0, X1, X2, s.xs[xi], s.ys[yi], gb, &acc);
+    }
+    float vals[14];
+    for (int i = 0; i < 9; ++i) vals[i] = acc.M[i];
+    vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2]; vals[12] = acc.gbx; vals[13] = acc.gby;
+    block_sum<14>(vals, s.red, s.tot);
+    if (threadIdx.x == 0) {
+        float gC[3], gth, gpx, gpy;
+        pose_backward(a.rc.cc, pc_local, s.tot, s.tot + 9, s.tot[12], s.tot[13], gC, &gth, &gpx, &gpy);
+        if (a.g_campos) { a.g_campos[3 * n] = gC[0]; a.g_campos[3 * n + 1] = gC[1]; a.g_campos[3 * n + 2] = gC[2]; }
+        if (a.g_theta) a.g_theta[n] = gth;
+        if (a.g_principal) { a.g_principal[2 * n] = gpx; a.g_principal[2 * n + 1] = gpy; }
+    }
+}
+
+extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                    const float* principal, int32_t n, const float* grad_maps, float* g_campos,
+                                    float* g_theta, float* g_principal, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!m || !campos || !theta || !grad_maps || n < 0) return fail(NEMO_ERR_INVALID, "nemo_render_backward: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    if (!m->memory_t) return fail(NEMO_ERR_STATE, "nemo_render_backward: mesh has no vertex memory");
+    RenderBwdArgs a;
+    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, &a.rc.L);
+    if (rcode) return rcode;
+    a.memory_t = m->memory_t; a.C = m->C;
+    a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
+    a.grad_maps = grad_maps; a.g_campos = g_campos; a.g_theta = g_theta; a.g_principal = g_principal;
+    if (set_lds_limit(render_backward_kernel, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(render_backward_kernel, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// clutter score
+// ------------------------------------------------------------------------------------------
+__global__ void clutter_kernel(const float* __restrict__ feat, const float* __restrict__ clutter, int C, int HW, int K,
+                               float* __restrict__ out) {
+    extern __shared__ float cl[];   // [K*C]
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) cl[i] = clutter[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* f = feat + (size_t)b * C * HW + p;
+    float best = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        float acc = 0.0f;
+        const float* ck = cl + k * C;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) acc = __builtin_fmaf(f[(size_t)c * HW], ck[c], acc);
+        best = (k == 0) ? acc : fmaxf(best, acc);
+    }
+    out[(size_t)b * HW + p] = best;
+}
+
+extern "C" int nemo_clutter_score(const float* feat, const float* clutter, int32_t B, int32_t C, int32_t HW, int32_t K,
+                                  float* out, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!feat || !clutter || !out || B < 0 || C <= 0 || HW <= 0 || K <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_clutter_score: bad argument");
+    if ((size_t)K * C * 4 > 64 * 1024) return fail(NEMO_ERR_UNSUPPORTED, "nemo_clutter_score: K*C too large");
+    dim3 grid((HW + 255) / 256, B), block(256);
+    hipLaunchKernelGGL(clutter_kernel, grid, block, (size_t)K * C * 4, (hipStream_t)stream, feat, clutter, C, HW, K, out);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense pose-grid scoring
+// ------------------------------------------------------------------------------------------
+constexpr int GS_TN = 8, GS_TB = 8, GS_PIX = 256;
+
+// partial[ptile][b][n] = sum over the tile's pixels of max(obj, clu) (or obj when clu == nullptr)
+__global__ __launch_bounds__(GS_PIX) void grid_score_kernel(const float* __restrict__ pre, const float* __restrict__ feat,
+                                                           const float* __restrict__ clu, int N, int B, int C, int HW,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[4][GS_TN * GS_TB];
+    const int p = blockIdx.x * GS_PIX + threadIdx.x;
+    const int n0 = blockIdx.y * GS_TN, b0 = blockIdx.z * GS_TB;
+    const bool valid = p < HW;
+    const int pc = valid ? p : HW - 1;
+    float acc[GS_TN][GS_TB];
+#pragma unroll
+    for (int i = 0; i < GS_TN; ++i)
+#pragma unroll
+        for (int j = 0; j < GS_TB; ++j) acc[i][j] = 0.0f;
+    const float* pp[GS_TN];
+    const float* fp[GS_TB];
+#pragma unroll
+    for (int i = 0; i < GS_TN; ++i) pp[i] = pre + (size_t)min(n0 + i, N - 1) * C * HW + pc;
+#pragma unroll
+    for (int j = 0; j < GS_TB; ++j) fp[j] = feat + (size_t)min(b0 + j, B - 1) * C * HW + pc;
+    for (int c = 0; c < C; ++c) {
+        float pv[GS_TN], fv[GS_TB];
+#pragma unroll
+        for (int i = 0; i < GS_TN; ++i) pv[i] = pp[i][(size_t)c * HW];
+#pragma unroll
+        for (int j = 0; j < GS_TB; ++j) fv[j] = fp[j][(size_t)c * HW];
+#pragma unroll
+        for (int i = 0; i < GS_TN; ++i)
+#pragma unroll
+            for (int j = 0; j < GS_TB; ++j) acc[i][j] = __builtin_fmaf(pv[i], fv[j], acc[i][j]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < GS_TB; ++j) {
+        float cl = 0.0f;
+        if (clu) cl = clu[(size_t)min(b0 + j, B - 1) * HW + pc];
+#pragma unroll
+        for (int i = 0; i < GS_TN; ++i) {
+            float v = clu ? fmaxf(acc[i][j], cl) : acc[i][j];
+            v = valid ? v : 0.0f;
+            v = wave_sum(v);
+            if (lane == 0) red[wave][i * GS_TB + j] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GS_TN * GS_TB) {
+        int i = threadIdx.x / GS_TB, j = threadIdx.x % GS_TB;
+        if (n0 + i < N && b0 + j < B) {
+            float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+            partial[((size_t)blockIdx.x * B + (b0 + j)) * N + (n0 + i)] = v;
+        }
+    }
+}
+
+// loss[b][n] = 1 - (sum_tiles partial / HW - sum_p clu / HW); argmin over n (first minimum).
+__global__ void grid_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ clu, int N, int B, int HW,
+                                     int ntiles, float* __restrict__ out_loss, int32_t* __restrict__ out_argmin,
+                                     float* __restrict__ out_min) {
+    __shared__ float sred[256];
+    __shared__ int ired[256];
+    __shared__ float clu_mean;
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s = 0.0f;
+    if (clu)
+        for (int p = t; p < HW; p += 256) s += clu[(size_t)b * HW + p];
+    sred[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sred[t] += sred[t + o];
+        __syncthreads();
+    }
+    if (t == 0) clu_mean = sred[0] / (float)HW;
+    __syncthreads();
+    float best = __builtin_inff();
+    int besti = 0x7FFFFFFF;
+    for (int n = t; n < N; n += 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < ntiles; ++k) acc += partial[((size_t)k * B + b) * N + n];
+        float loss = 1.0f - (acc / (float)HW - clu_mean);
+        if (out_loss) out_loss[(size_t)b * N + n] = loss;
+        if (loss < best || (loss == best && n < besti)) { best = loss; besti = n; }
+    }
+    sred[t] = best; ired[t] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            float ob = sred[t + o]; int oi = ired[t + o];
+            if (ob < sred[t] || (ob == sred[t] && oi < ired[t])) { sred[t] = ob; ired[t] = oi; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out_argmin[b] = ired[0] == 0x7FFFFFFF ? 0 : ired[0];
+        if (out_min) out_min[b] = sred[0];
+    }
+}
+
+extern "C" size_t nemo_grid_score_workspace(int32_t N, int32_t B, int32_t HW) {
+    if (N <= 0 || B <= 0 || HW <= 0) return 0;
+    size_t tiles = (size_t)(HW + GS_PIX - 1) / GS_PIX;
+    return tiles * (size_t)B * (size_t)N * sizeof(float);
+}
+
+extern "C" int nemo_grid_score(const float* pre, const float* feat, const float* clu, int32_t N, int32_t B, int32_t C,
+                               int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!pre || !feat || !out_argmin || N <= 0 || B < 0 || C <= 0 || HW <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score: bad argument");
+    size_t need = nemo_grid_score_workspace(N, B, HW);
+    if (!workspace || workspace_bytes < need)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    int tiles = (HW + GS_PIX - 1) / GS_PIX;
+    dim3 grid(tiles, (N + GS_TN - 1) / GS_TN, (B + GS_TB - 1) / GS_TB);
+    if (grid.y > 65535 || grid.z > 65535) return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grid_score_kernel, grid, dim3(GS_PIX), 0, st, pre, feat, clu, N, B, C, HW, (float*)workspace);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)workspace, clu, N, B, HW, tiles,
+                       out_loss, out_argmin, out_min);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// vertex similarity (fast_inference)
+// ------------------------------------------------------------------------------------------
+__global__ void vertex_similarity_kernel(const float* __restrict__ table, const float* __restrict__ clu,
+                                         const int32_t* __restrict__ boxes, int V, int H, int W, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    int r0 = 0, r1 = H, c0 = 0, c1 = W;
+    if (boxes) { r0 = boxes[4 * b]; r1 = boxes[4 * b + 1]; c0 = boxes[4 * b + 2]; c1 = boxes[4 * b + 3]; }
+    r0 = max(r0, 0); c0 = max(c0, 0); r1 = min(r1, H); c1 = min(c1, W);
+    const int bw = max(c1 - c0, 0), bh = max(r1 - r0, 0), np = bw * bh, HW = H * W;
+    float s = 0.0f;
+    for (int q = threadIdx.x; q < np; q += blockDim.x) {
+        int p = (r0 + q / bw) * W + c0 + q % bw;
+        const float* t = table + (size_t)b * V * HW + p;
+        float best = -__builtin_inff();
+        for (int v = 0; v < V; ++v) best = fmaxf(best, t[(size_t)v * HW]);
+        s += fmaxf(best, clu[(size_t)b * HW + p]);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = (((red[0] + red[1]) + red[2]) + red[3]) / (float)np;
+}
+
+extern "C" int nemo_vertex_similarity(nemo_mesh_t m, const float* table, const float* clu, const int32_t* boxes, int32_t B,
+                                      int32_t H, int32_t W, float* out, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!m || !table || !clu || !out || B < 0 || H <= 0 || W <= 0) return fail(NEMO_ERR_INVALID, "nemo_vertex_similarity: bad argument");
+    hipLaunchKernelGGL(vertex_similarity_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, table, clu, boxes, m->V, H, W, out);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pose optimisation
+// ------------------------------------------------------------------------------------------
+struct OptState {
+    float P[6], m[6], v[6];
+    double lr, b1p, b2p;
+    float sum_clu, first_loss, last_loss;
+};
+
+struct SolveArgs {
+    RasterCtx rc;
+    const float* table; const float* clu; const int32_t* hyp_to_image;
+    const float* init_campos; const float* init_theta; const float* init_principal;
+    float def_px, def_py;
+    int n_img; float inv_norm; int dof;
+    int steps, lr_every;
+    double lr, beta1, beta2, eps, gamma;
+    float* out_pose; float* out_hist;
+};
+
+__global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds s = carve(smem, a.rc.L);
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
+    const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
+    const float* tab = a.table + (size_t)img * V * HW;
+    const float* clu = a.clu + (size_t)img * HW;
+    raster_prologue(a.rc, s);
+
+    // optimiser state lives in LDS; only thread 0 touches it
+    OptState* os = (OptState*)(smem + a.rc.L.opt);
+    const int np = a.dof == 6 ? 6 : 4;
+    if (tid == 0) {
+        for (int k = 0; k < 6; ++k) { os->m[k] = 0.0f; os->v[k] = 0.0f; }
+        os->P[0] = a.init_campos[3 * h]; os->P[1] = a.init_campos[3 * h + 1]; os->P[2] = a.init_campos[3 * h + 2];
+        os->P[3] = a.init_theta[h];
+        os->P[4] = a.init_principal ? a.init_principal[2 * h] : a.def_px;
+        os->P[5] = a.init_principal ? a.init_principal[2 * h + 1] : a.def_py;
+        os->lr = a.lr; os->b1p = 1.0; os->b2p = 1.0;
+        os->sum_clu = 0.0f; os->first_loss = 0.0f; os->last_loss = 0.0f;
+    }
+    const float fHW = (float)HW;
+
+    for (int step = 0; step < a.steps; ++step) {
+        if (tid == 0) pose_setup(a.rc.cc, os->P, os->P[3], os->P[4], os->P[5], s.pc);
+        __syncthreads();
+        project_and_rasterize(a.rc, s);
+
+        float vals[16];
+        {
+            PixelGrad acc;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
+            acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
+            float smax = 0.0f, sclu = 0.0f;
+            for (int p = tid; p < HW; p += blockDim.x) {
+                const unsigned long long key = s.zbuf[p];
+                const float cl = clu[p];
+                float obj = 0.0f;
+                if (key != kEmptyKey) {
+                    int f = (int)(key & 0xFFFFFFFFull), i0, i1, i2;
+                    load_face(a.rc, s, f, &i0, &i1, &i2);
+                    float d0 = tab[(size_t)i0 * HW + p], d1 = tab[(size_t)i1 * HW + p], d2 = tab[(size_t)i2 * HW + p];
+                    FaceVerts fv = face_verts(s, i0, i1, i2);
+                    int yi = p / W, xi = p - yi * W;
+                    float xf = s.xs[xi], yf = s.ys[yi];
+                    float b[3], pz;
+                    face_eval(fv, xf, yf, b, &pz);
+                    obj = (b[0] * d0 + b[1] * d1) + b[2] * d2;
+                    float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+                    if (mk != 0.0f) {
+                        float g = -mk * a.inv_norm;
+                        float gb[3] = {g * d0, g * d1, g * d2};
+                        float X0[3] = {s.vX[i0], s.vY[i0], s.vZ[i0]}, X1[3] = {s.vX[i1], s.vY[i1], s.vZ[i1]},
+                              X2[3] = {s.vX[i2], s.vY[i2], s.vZ[i2]};
+                        pixel_backward(a.rc.cc, fv, X0, X1, X2, xf, yf, gb, &acc);
+                    }
+                }
+                smax += fmaxf(obj, cl);
+                sclu += cl;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) vals[i] = acc.M[i];
+            vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2];
+            vals[12] = acc.gbx; vals[13] = acc.gby; vals[14] = smax; vals[15] = sclu;
+        }
+        block_sum<16>(vals, s.red, s.tot);
+
+        if (tid == 0) {
+            if (step == 0) os->sum_clu = s.tot[15];
+            float loss = 1.0f - (s.tot[14] / fHW - os->sum_clu / fHW);
+            if (step == 0) os->first_loss = loss;
+            os->last_loss = loss;
+            if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
+            float g[6];
+            pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
+            // torch.optim.Adam (single-tensor path): lerp for the first moment, mul+addcmul for the
+            // second, bias corrections and step size in double, then addcdiv.
+            os->b1p *= a.beta1; os->b2p *= a.beta2;
+            const double bc1 = 1.0 - os->b1p, bc2 = 1.0 - os->b2p;
+            const float step_size = (float)(-(os->lr / bc1));
+            const float bc2s = (float)sqrt(bc2);
+            const float w1 = (float)(1.0 - a.beta1), b2f = (float)a.beta2, w2 = (float)(1.0 - a.beta2), epsf = (float)a.eps;
+            for (int k = 0; k < np; ++k) {
+                float gk = g[k];
+                float mk = os->m[k], vk = os->v[k];
+                float diff = gk - mk;
+                mk = w1 < 0.5f ? mk + w1 * diff : gk - diff * (1.0f - w1);
+                vk = vk * b2f + (w2 * gk) * gk;
+                float denom = sqrtf(vk) / bc2s + epsf;
+                os->P[k] = os->P[k] + step_size * (mk / denom);
+                os->m[k] = mk; os->v[k] = vk;
+            }
+            if (a.lr_every > 0 && (step + 1) % a.lr_every == 0) os->lr *= a.gamma;
+        }
+        // the next iteration's first barrier orders these LDS accesses before s.tot / s.pc / s.zbuf are reused
+    }
+    if (tid == 0) {
+        float* o = a.out_pose + (size_t)h * 8;
+        for (int k = 0; k < 6; ++k) o[k] = os->P[k];
+        o[6] = os->last_loss; o[7] = os->first_loss;
+    }
+}
+
+extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+                          const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
+                          const float* init_principal, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
+                          const nemo_adam* opt, float* out_pose, float* out_hist, void* stream) {
+    if (n_hyp == 0) return NEMO_OK;
+    if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_solve: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    if (dof != 3 && dof != 4 && dof != 6) return fail(NEMO_ERR_INVALID, "nemo_solve: dof must be 3, 4 or 6");
+    if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve: negative step count");
+    if (n_hyp == 0) return NEMO_OK;
+    SolveArgs a;
+    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, &a.rc.L);
+    if (rcode) return rcode;
+    a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
+    a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_principal;
+    a.def_px = cam->px; a.def_py = cam->py;
+    a.n_img = n_img;
+    a.inv_norm = 1.0f / ((float)global_batch * (float)(cam->H * cam->W));
+    a.dof = dof;
+    a.steps = opt->steps; a.lr_every = opt->lr_every;
+    a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
+    a.out_pose = out_pose; a.out_hist = out_hist;
+    if (set_lds_limit(solve_kernel, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(solve_kernel, dim3(n_hyp), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// spherical read-out
+// ------------------------------------------------------------------------------------------
+__global__ void spherical_kernel(const float* __restrict__ campos, int n, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = campos[3 * i], y = campos[3 * i + 1], z = campos[3 * i + 2];
+    float d = sqrtf((x * x + y * y) + z * z);
+    const double pi = 3.14159265358979323846;
+    // atan(x/z) % pi + pi * (x < 0), python-style remainder (result in [0, pi))
+    float at = (float)atan((double)(x / z));
+    float r = at - floorf(at / (float)pi) * (float)pi;
+    if (r < 0.0f) r += (float)pi;
+    if (r >= (float)pi) r -= (float)pi;
+    float azim = r + (x < 0.0f ? (float)pi : 0.0f);
+    float elev = (float)asin((double)(y / d));
+    out[3 * i] = d; out[3 * i + 1] = elev; out[3 * i + 2] = azim;
+}
+
+extern "C" int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!campos || !out || n < 0) return fail(NEMO_ERR_INVALID, "nemo_spherical_angles: bad argument");
+    hipLaunchKernelGGL(spherical_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, campos, n, out);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity table (kernel in table_gemm.hip)
+// ------------------------------------------------------------------------------------------
+namespace nemo {
+int launch_table_gemm(const float* memT, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
+}
+
+extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B, int32_t HW, float* table, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!m || !feat || !table || B < 0 || HW <= 0) return fail(NEMO_ERR_INVALID, "nemo_similarity_table: bad argument");
+    if (!m->memory_t) return fail(NEMO_ERR_STATE, "nemo_similarity_table: mesh has no vertex memory");
+    if (nemo::launch_table_gemm(m->memory_t, feat, table, m->V, m->C, HW, B, (hipStream_t)stream))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table: too many tiles for one launch");
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}

@@ -1,0 +1,235 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of include/nemo_hip.h).
+
+Each wrapper allocates its outputs with torch (device memory plumbing), passes raw pointers and the
+current stream, and raises on a non-zero return code.  No arithmetic happens here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NemoAdam, NemoCamera, check, f32c, ptr, stream_ptr
+
+
+class Camera:
+    """Host-side value of the C struct nemo_camera."""
+
+    def __init__(self, H, W, focal, px=None, py=None):
+        self.H, self.W, self.focal = int(H), int(W), float(focal)
+        self.px = float(W // 2) if px is None else float(px)
+        self.py = float(H // 2) if py is None else float(py)
+
+    def c(self):
+        return NemoCamera(self.H, self.W, self.focal, self.px, self.py)
+
+
+class MeshHandle:
+    """Owner of a nemo_mesh_t (device copies of verts / faces / vertex memory)."""
+
+    def __init__(self, verts, faces):
+        lib = _lib.load()
+        if not verts.is_cuda:
+            raise RuntimeError("MeshHandle needs device tensors")
+        self.device = verts.device
+        v = f32c(verts)
+        f = faces.detach().to(torch.int32).contiguous()
+        if v.dim() != 2 or v.shape[1] != 3 or f.dim() != 2 or f.shape[1] != 3:
+            raise ValueError("verts must be [V,3] and faces [F,3]")
+        if f.numel() and (int(f.min()) < 0 or int(f.max()) >= v.shape[0]):
+            raise ValueError("face index out of range")
+        self.V, self.F, self.C = v.shape[0], f.shape[0], 0
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.nemo_mesh_create(ptr(v), ptr(f, torch.int32), self.V, self.F, C.byref(h)), "nemo_mesh_create")
+        self._h = h
+
+    def set_memory(self, memory):
+        lib = _lib.load()
+        mem = f32c(memory.to(self.device))
+        if mem.dim() != 2 or mem.shape[0] != self.V:
+            raise ValueError(f"memory must be [V={self.V}, C], got {tuple(mem.shape)}")
+        with torch.cuda.device(self.device):
+            check(lib.nemo_mesh_set_memory(self._h, ptr(mem), mem.shape[1], stream_ptr()), "nemo_mesh_set_memory")
+            torch.cuda.current_stream().synchronize()   # `mem` may be a temporary
+        self.C = mem.shape[1]
+
+    @property
+    def h(self):
+        if self._h is None:
+            raise RuntimeError("mesh handle already destroyed")
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.load().nemo_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _pose_args(campos, theta, principal):
+    cp = f32c(campos).reshape(-1, 3)
+    n = cp.shape[0]
+    th = f32c(theta).reshape(-1)
+    if th.numel() != n:
+        raise ValueError(f"theta has {th.numel()} entries for {n} camera positions")
+    pr = None
+    if principal is not None:
+        pr = f32c(principal).reshape(-1, 2)
+        if pr.shape[0] == 1 and n > 1:
+            pr = pr.expand(n, 2).contiguous()
+        if pr.shape[0] != n:
+            raise ValueError(f"principal has {pr.shape[0]} rows for {n} cameras")
+    return cp, th, pr, n
+
+
+def project(mesh, cam, campos, theta, principal=None):
+    """-> (RT [n,12], proj [n,V,5]): R row-major + T, and view X,Y,Z + NDC x,y per vertex."""
+    lib = _lib.load()
+    cp, th, pr, n = _pose_args(campos, theta, principal)
+    rt = torch.empty(n, 12, device=cp.device)
+    proj = torch.empty(n, mesh.V, 5, device=cp.device)
+    cc = cam.c()
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_project(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, ptr(rt), ptr(proj), stream_ptr()),
+              "nemo_project")
+    return rt, proj
+
+
+def render(mesh, cam, campos, theta, principal=None, maps=True, fragments=False):
+    """-> dict(maps [n,C,H,W], pix_to_face [n,H,W] i32, bary [n,H,W,3], zbuf [n,H,W]) (requested keys)."""
+    lib = _lib.load()
+    cp, th, pr, n = _pose_args(campos, theta, principal)
+    dev = cp.device
+    out = {}
+    if maps:
+        out["maps"] = torch.empty(n, mesh.C, cam.H, cam.W, device=dev)
+    if fragments:
+        out["pix_to_face"] = torch.empty(n, cam.H, cam.W, dtype=torch.int32, device=dev)
+        out["bary"] = torch.empty(n, cam.H, cam.W, 3, device=dev)
+        out["zbuf"] = torch.empty(n, cam.H, cam.W, device=dev)
+    cc = cam.c()
+    with torch.cuda.device(dev):
+        check(lib.nemo_render(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, ptr(out.get("maps")),
+                              ptr(out.get("pix_to_face"), torch.int32), ptr(out.get("bary")), ptr(out.get("zbuf")),
+                              stream_ptr()), "nemo_render")
+    return out
+
+
+def render_backward(mesh, cam, campos, theta, principal, grad_maps, want_principal=False):
+    """-> (grad_campos [n,3], grad_theta [n], grad_principal [n,2] or None)."""
+    lib = _lib.load()
+    cp, th, pr, n = _pose_args(campos, theta, principal)
+    gm = f32c(grad_maps)
+    if tuple(gm.shape) != (n, mesh.C, cam.H, cam.W):
+        raise ValueError(f"grad_maps must be {(n, mesh.C, cam.H, cam.W)}, got {tuple(gm.shape)}")
+    gC = torch.empty(n, 3, device=cp.device)
+    gT = torch.empty(n, device=cp.device)
+    gP = torch.empty(n, 2, device=cp.device) if want_principal else None
+    cc = cam.c()
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_render_backward(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, ptr(gm), ptr(gC), ptr(gT),
+                                       ptr(gP), stream_ptr()), "nemo_render_backward")
+    return gC, gT, gP
+
+
+def clutter_score(feature_map, clutter):
+    """feature_map [B,C,H,W], clutter [K,C] -> [B,H,W] (max over the K clutter vectors)."""
+    lib = _lib.load()
+    fm = f32c(feature_map)
+    cl = f32c(clutter).reshape(-1, fm.shape[1])
+    B, Cc, H, W = fm.shape
+    out = torch.empty(B, H, W, device=fm.device)
+    with torch.cuda.device(fm.device):
+        check(lib.nemo_clutter_score(ptr(fm), ptr(cl), B, Cc, H * W, cl.shape[0], ptr(out), stream_ptr()),
+              "nemo_clutter_score")
+    return out
+
+
+def grid_score(pre_rendered, feature_map, clutter_score_map=None):
+    """pre_rendered [N,C,H,W], feature_map [B,C,H,W], clutter_score_map [B,H,W] or None
+    -> (loss [B,N], argmin [B] int32, min_loss [B])."""
+    lib = _lib.load()
+    pre = f32c(pre_rendered)
+    fm = f32c(feature_map)
+    N, Cc, H, W = pre.shape
+    B = fm.shape[0]
+    if tuple(fm.shape[1:]) != (Cc, H, W):
+        raise ValueError(f"feature_map {tuple(fm.shape)} does not match pre-rendered maps {tuple(pre.shape)}")
+    clu = None if clutter_score_map is None else f32c(clutter_score_map).reshape(B, H * W)
+    loss = torch.empty(B, N, device=fm.device)
+    amin = torch.empty(B, dtype=torch.int32, device=fm.device)
+    mn = torch.empty(B, device=fm.device)
+    nbytes = lib.nemo_grid_score_workspace(N, B, H * W)
+    ws = torch.empty(max(nbytes, 4) // 4, device=fm.device)
+    with torch.cuda.device(fm.device):
+        check(lib.nemo_grid_score(ptr(pre), ptr(fm), ptr(clu), N, B, Cc, H * W, ptr(loss), ptr(amin, torch.int32),
+                                  ptr(mn), ptr(ws), nbytes, stream_ptr()), "nemo_grid_score")
+    return loss, amin, mn
+
+
+def similarity_table(mesh, feature_map, out=None):
+    """feature_map [B,C,H,W] -> table [B,V,H*W]."""
+    lib = _lib.load()
+    fm = f32c(feature_map)
+    B, Cc, H, W = fm.shape
+    if Cc != mesh.C:
+        raise ValueError(f"feature map has {Cc} channels, vertex memory has {mesh.C}")
+    if out is None:
+        out = torch.empty(B, mesh.V, H * W, device=fm.device)
+    with torch.cuda.device(fm.device):
+        check(lib.nemo_similarity_table(mesh.h, ptr(fm), B, H * W, ptr(out), stream_ptr()), "nemo_similarity_table")
+    return out
+
+
+def vertex_similarity(mesh, table, clu, H, W, boxes=None):
+    """table [B,V,HW], clu [B,H,W], boxes [B,4] int32 (r0,r1,c0,c1) or None -> [B]."""
+    lib = _lib.load()
+    B = table.shape[0]
+    out = torch.empty(B, device=table.device)
+    bx = None if boxes is None else boxes.to(device=table.device, dtype=torch.int32).contiguous()
+    with torch.cuda.device(table.device):
+        check(lib.nemo_vertex_similarity(mesh.h, ptr(table), ptr(f32c(clu)), ptr(bx, torch.int32), B, H, W, ptr(out),
+                                         stream_ptr()), "nemo_vertex_similarity")
+    return out
+
+
+def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, hyp_to_image=None, global_batch=None,
+          dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, lr_gamma=0.2, lr_every=None, history=False):
+    """Runs the whole Adam loop on device.  -> (pose [n_hyp,8], loss_hist [n_hyp,steps] or None).
+    pose columns: cx, cy, cz, theta, px, py, score (last forward), first-forward loss."""
+    lib = _lib.load()
+    cp, th, pr, n_hyp = _pose_args(init_campos, init_theta, init_principal)
+    n_img = table.shape[0]
+    if hyp_to_image is None and n_hyp != n_img:
+        raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
+    h2i = None if hyp_to_image is None else hyp_to_image.to(device=cp.device, dtype=torch.int32).contiguous()
+    if h2i is not None and h2i.numel() and (int(h2i.min()) < 0 or int(h2i.max()) >= n_img):
+        raise ValueError("hyp_to_image out of range")
+    clu2 = f32c(clu).reshape(n_img, -1)
+    if tuple(table.shape) != (n_img, mesh.V, cam.H * cam.W) or clu2.shape[1] != cam.H * cam.W:
+        raise ValueError("table / clutter shapes do not match the mesh and camera")
+    opt = NemoAdam(int(steps), int(lr_every if lr_every is not None else max(steps // 3, 0)), float(lr), float(betas[0]),
+                   float(betas[1]), float(eps), float(lr_gamma))
+    out = torch.empty(n_hyp, 8, device=cp.device)
+    hist = torch.empty(n_hyp, steps, device=cp.device) if history else None
+    cc = cam.c()
+    gb = int(global_batch if global_batch is not None else n_img)
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_solve(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(cp), ptr(th), ptr(pr),
+                             n_hyp, n_img, gb, int(dof), C.byref(opt), ptr(out), ptr(hist), stream_ptr()), "nemo_solve")
+    return out, hist
+
+
+def spherical_angles(campos):
+    """campos [n,3] -> [n,3] = distance, elevation, azimuth."""
+    lib = _lib.load()
+    cp = f32c(campos).reshape(-1, 3)
+    out = torch.empty_like(cp)
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_spherical_angles(ptr(cp), cp.shape[0], ptr(out), stream_ptr()), "nemo_spherical_angles")
+    return out
