@@ -93,5 +93,7 @@ def ptr(t, dtype=torch.float32):
 
 
 def f32c(t):
-    """float32 contiguous device copy/view of `t` (detached)."""
+    """float32 contiguous device copy/view of `t` (detached).  CPU tensors are refused: no CPU path."""
+    if not t.is_cuda:
+        raise RuntimeError("nemo_amd kernels need device tensors (got a CPU tensor); there is no CPU path")
     return t.detach().to(torch.float32).contiguous()

@@ -166,57 +166,15 @@ __device__ inline int clamp_index(float v, int n, int nan_val) {
     return (int)v;
 }
 
-// Rasterise one face into the LDS depth/face key buffer (atomic min on (depth bits << 32 | face)):
-// the winner per pixel is the face with the smallest interpolated depth, ties to the smaller
-// face index, exactly as a serial scan over the faces in order would leave it.
-// xs_ndc[W] / ys_ndc[H]: NDC of every pixel column / row centre.
-__device__ inline void raster_face(int face, const FaceVerts& f, int H, int W, const float* xs_ndc,
-                                   const float* ys_ndc, unsigned long long* zbuf) {
-    float zmax = fmaxf(fmaxf(f.z0, f.z1), f.z2);
-    float farea = edge_fn(f.x0, f.y0, f.x1, f.y1, f.x2, f.y2);
-    if (zmax < kEps) return;
-    if (farea <= kEps && farea >= -kEps) return;
-    if (!(farea == farea)) { /* NaN geometry never covers a pixel */ return; }
-    float xmin = fminf(fminf(f.x0, f.x1), f.x2), xmax = fmaxf(fmaxf(f.x0, f.x1), f.x2);
-    float ymin = fminf(fminf(f.y0, f.y1), f.y2), ymax = fmaxf(fmaxf(f.y0, f.y1), f.y2);
-    // conservative pixel range from the inverse of pix_to_ndc, widened by one pixel; the exact
-    // bounding-box test below decides.
-    float rx = ndc_range(W, H), ry = ndc_range(H, W);
-    float ox = rx / 2.0f, oy = ry / 2.0f;
-    float jx_lo = ((xmin + ox) * (float)W - ox) / rx - 1.5f;
-    float jx_hi = ((xmax + ox) * (float)W - ox) / rx + 1.5f;
-    float jy_lo = ((ymin + oy) * (float)H - oy) / ry - 1.5f;
-    float jy_hi = ((ymax + oy) * (float)H - oy) / ry + 1.5f;
-    if (jx_hi < 0.0f || jy_hi < 0.0f || jx_lo > (float)(W - 1) || jy_lo > (float)(H - 1)) return;
-    int jx0 = clamp_index(jx_lo, W, 0), jx1 = clamp_index(jx_hi, W, W - 1);
-    int jy0 = clamp_index(jy_lo, H, 0), jy1 = clamp_index(jy_hi, H, H - 1);
-    float area = edge_fn(f.x2, f.y2, f.x0, f.y0, f.x1, f.y1) + kEps;
-    bool zpos = f.z0 > 0.0f && f.z1 > 0.0f && f.z2 > 0.0f;
-    // flipped index j <-> pixel index: xi = W-1-j, yi = H-1-j
-    for (int jy = jy0; jy <= jy1; ++jy) {
-        int yi = H - 1 - jy;
-        float yf = ys_ndc[yi];
-        if (yf > ymax || yf < ymin) continue;
-        for (int jx = jx0; jx <= jx1; ++jx) {
-            int xi = W - 1 - jx;
-            float xf = xs_ndc[xi];
-            if (xf > xmax || xf < xmin) continue;
-            if (zpos) {
-                // cheap exact rejection: with all depths positive, a non-positive edge function
-                // (relative to the sign of the area) gives a non-positive barycentric.
-                float e0 = edge_fn(xf, yf, f.x1, f.y1, f.x2, f.y2);
-                float e1 = edge_fn(xf, yf, f.x2, f.y2, f.x0, f.y0);
-                float e2 = edge_fn(xf, yf, f.x0, f.y0, f.x1, f.y1);
-                if (area > 0.0f && (e0 <= 0.0f || e1 <= 0.0f || e2 <= 0.0f)) continue;
-                if (area < 0.0f && (e0 >= 0.0f || e1 >= 0.0f || e2 >= 0.0f)) continue;
-            }
-            float b[3], pz;
-            face_eval(f, xf, yf, b, &pz);
-            if (pz < 0.0f) continue;
-            if (!(b[0] > 0.0f && b[1] > 0.0f && b[2] > 0.0f)) continue;
-            atomicMin(&zbuf[yi * W + xi], depth_key(pz, face));
-        }
-    }
+// Full coverage test of one (face, pixel) pair and depth-buffer update: atomic min on
+// (depth bits << 32 | face), i.e. nearest depth wins and ties go to the smaller face index, exactly as
+// a serial scan over the faces in order would leave it.
+__device__ inline void eval_and_min(int face, const FaceVerts& f, int p, float xf, float yf, unsigned long long* zbuf) {
+    float b[3], pz;
+    face_eval(f, xf, yf, b, &pz);
+    if (pz < 0.0f) return;
+    if (!(b[0] > 0.0f && b[1] > 0.0f && b[2] > 0.0f)) return;
+    atomicMin(&zbuf[p], depth_key(pz, face));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -291,6 +249,66 @@ __device__ inline void pixel_backward(const CamConst& cc, const FaceVerts& f, co
         acc->gby += gys[i];
     }
 }
+
+// Forward + backward of one covered pixel for the optimisation loop (values only need the loss
+// tolerance, not bit parity: reciprocals are the 1-ulp hardware form and fma contraction is allowed).
+// d[3]: similarity of the face's three vertices with the image feature at this pixel.
+// Returns obj = sum_i b_i d_i; if gscale != 0 accumulates the pose-gradient sums for dL/dobj = gscale.
+#pragma clang fp contract(fast)
+__device__ inline float pixel_score_and_grad(const CamConst& cc, const FaceVerts& f, const float* Xv0, const float* Xv1,
+                                             const float* Xv2, float xf, float yf, const float* d, float cl,
+                                             float inv_norm, PixelGrad* acc) {
+    float area = edge_fn(f.x2, f.y2, f.x0, f.y0, f.x1, f.y1) + kEps;
+    float inv_area = __builtin_amdgcn_rcpf(area);
+    float e0 = edge_fn(xf, yf, f.x1, f.y1, f.x2, f.y2);
+    float e1 = edge_fn(xf, yf, f.x2, f.y2, f.x0, f.y0);
+    float e2 = edge_fn(xf, yf, f.x0, f.y0, f.x1, f.y1);
+    float w0 = e0 * inv_area, w1 = e1 * inv_area, w2 = e2 * inv_area;
+    float t0 = w0 * f.z1 * f.z2, t1 = f.z0 * w1 * f.z2, t2 = f.z0 * f.z1 * w2;
+    float den_raw = (t0 + t1) + t2;
+    bool clamped = !(den_raw > kEps);
+    float den = clamped ? kEps : den_raw;
+    float inv_den = __builtin_amdgcn_rcpf(den);
+    float b0 = t0 * inv_den, b1 = t1 * inv_den, b2 = t2 * inv_den;
+    float obj = (b0 * d[0] + b1 * d[1]) + b2 * d[2];
+    float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+    if (mk == 0.0f) return obj;
+    float g = -mk * inv_norm;
+    float gb0 = g * d[0], gb1 = g * d[1], gb2 = g * d[2];
+    float dot = gb0 * b0 + gb1 * b1 + gb2 * b2;
+    float gden = clamped ? 0.0f : -dot * inv_den;
+    float gt0 = gb0 * inv_den + gden, gt1 = gb1 * inv_den + gden, gt2 = gb2 * inv_den + gden;
+    float gw0 = gt0 * f.z1 * f.z2, gw1 = gt1 * f.z0 * f.z2, gw2 = gt2 * f.z0 * f.z1;
+    float gz0 = gt1 * w1 * f.z2 + gt2 * f.z1 * w2;
+    float gz1 = gt0 * w0 * f.z2 + gt2 * f.z0 * w2;
+    float gz2 = gt0 * w0 * f.z1 + gt1 * f.z0 * w1;
+    float ge0 = gw0 * inv_area, ge1 = gw1 * inv_area, ge2 = gw2 * inv_area;
+    float garea = -(gw0 * w0 + gw1 * w1 + gw2 * w2) * inv_area;
+    float gx0 = ge1 * -(yf - f.y2) + ge2 * (yf - f.y1) + garea * (f.y2 - f.y1);
+    float gy0 = ge1 * (xf - f.x2) + ge2 * (f.x1 - xf) + garea * (f.x1 - f.x2);
+    float gx1 = ge0 * (yf - f.y2) + ge2 * -(yf - f.y0) + garea * -(f.y2 - f.y0);
+    float gy1 = ge0 * (f.x2 - xf) + ge2 * (xf - f.x0) + garea * (f.x2 - f.x0);
+    float gx2 = ge0 * -(yf - f.y1) + ge1 * (yf - f.y0) + garea * (f.y1 - f.y0);
+    float gy2 = ge0 * (xf - f.x1) + ge1 * (f.x0 - xf) + garea * -(f.x1 - f.x0);
+    const float* Xs[3] = {Xv0, Xv1, Xv2};
+    float gxs[3] = {gx0, gx1, gx2}, gys[3] = {gy0, gy1, gy2}, gzs[3] = {gz0, gz1, gz2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float* X = Xs[i];
+        float iz = __builtin_amdgcn_rcpf(X[2]);
+        float gX = gxs[i] * cc.a * iz;
+        float gY = gys[i] * cc.a * iz;
+        float gZ = gzs[i] - (gX * X[0] + gY * X[1]) * iz;
+        acc->M[0] += X[0] * gX; acc->M[1] += X[0] * gY; acc->M[2] += X[0] * gZ;
+        acc->M[3] += X[1] * gX; acc->M[4] += X[1] * gY; acc->M[5] += X[1] * gZ;
+        acc->M[6] += X[2] * gX; acc->M[7] += X[2] * gY; acc->M[8] += X[2] * gZ;
+        acc->S[0] += gX; acc->S[1] += gY; acc->S[2] += gZ;
+        acc->gbx += gxs[i];
+        acc->gby += gys[i];
+    }
+    return obj;
+}
+#pragma clang fp contract(off)
 
 // From the reduced sums to the gradient of (C[3], theta, px, py).
 __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, const float* M, const float* S, float gbx,

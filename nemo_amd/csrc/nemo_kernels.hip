@@ -19,7 +19,7 @@
 #include <new>
 
 #include "../../include/nemo_hip.h"
-#include "geom.h"
+#include "raster.h"
 
 #pragma clang fp contract(off)
 
@@ -126,87 +126,12 @@ extern "C" int nemo_mesh_info(nemo_mesh_t m, int32_t* V, int32_t* F, int32_t* C)
 }
 
 // ------------------------------------------------------------------------------------------
-// wave / block reductions (fixed order => bitwise reproducible)
+// LDS plan of the rasterising kernels (layout and front end: raster.h)
 // ------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ inline float dpp_add(float v) {
-    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-    return v + __int_as_float(t);
-}
-
-// Sum over the 64 lanes of a wave; every lane returns the total.
-__device__ inline float wave_sum(float v) {
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror
-    float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return ((r0 + r1) + r2) + r3;
-}
-
-// Reduce NV values per thread over the whole block.  red: LDS scratch [nwaves][NV]; tot: LDS [NV].
-// After the call tot[k] holds the block total (visible to all threads).
-template <int NV>
-__device__ inline void block_sum(float* vals, float* red, float* tot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        float s = wave_sum(vals[k]);
-        if (lane == 0) red[wave * NV + k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        float s = 0.0f;
-        for (int w = 0; w < nw; ++w) s += red[w * NV + threadIdx.x];
-        tot[threadIdx.x] = s;
-    }
-    __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS layout of the rasterising kernels
-// ------------------------------------------------------------------------------------------
-struct LdsLayout {
-    int zbuf;     // u64 [HW]
-    int vX, vY, vZ, vxn, vyn;   // f32 [V] each
-    int faces;    // i32 [F*3] (or -1: read faces from global memory)
-    int xs, ys;   // f32 [W], [H]
-    int red;      // f32 [16 waves * 16]
-    int tot;      // f32 [16]
-    int pc;       // PoseCam
-    int opt;      // OptState (solve kernel)
-    int total;
-};
-
-static inline int align16(int x) { return (x + 15) & ~15; }
-
-static LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
-    LdsLayout L;
-    int o = 0;
-    L.zbuf = o; o = align16(o + 8 * H * W);
-    L.vX = o; o = align16(o + 4 * V);
-    L.vY = o; o = align16(o + 4 * V);
-    L.vZ = o; o = align16(o + 4 * V);
-    L.vxn = o; o = align16(o + 4 * V);
-    L.vyn = o; o = align16(o + 4 * V);
-    if (faces_in_lds) { L.faces = o; o = align16(o + 12 * F); } else L.faces = -1;
-    L.xs = o; o = align16(o + 4 * W);
-    L.ys = o; o = align16(o + 4 * H);
-    L.red = o; o = align16(o + 4 * 16 * 16);
-    L.tot = o; o = align16(o + 4 * 16);
-    L.pc = o; o = align16(o + (int)sizeof(PoseCam));
-    L.opt = o; o = align16(o + 256);
-    L.total = o;
-    return L;
-}
-
-constexpr int kMaxLds = 160 * 1024;
-constexpr int kRasterThreads = 1024;
-
 static int plan_layout(int H, int W, int V, int F, LdsLayout* L) {
+    if (H > kMaxSide || W > kMaxSide || F >= kMaxFaces)
+        return fail(NEMO_ERR_UNSUPPORTED, "map %dx%d / %d faces exceed the rasteriser's limits (%d x %d pixels, %d faces)", H, W, F,
+                    kMaxSide, kMaxSide, kMaxFaces - 1);
     *L = make_layout(H, W, V, F, true);
     if (L->total > kMaxLds) *L = make_layout(H, W, V, F, false);
     if (L->total > kMaxLds)
@@ -214,86 +139,6 @@ static int plan_layout(int H, int W, int V, int F, LdsLayout* L) {
                     "map %dx%d with %d vertices needs %d bytes of LDS per workgroup (limit %d)", H, W, V,
                     L->total, kMaxLds);
     return NEMO_OK;
-}
-
-struct RasterCtx {
-    const float* verts;
-    const int32_t* faces;
-    int V, F;
-    CamConst cc;
-    LdsLayout L;
-};
-
-struct Lds {
-    unsigned long long* zbuf;
-    float *vX, *vY, *vZ, *vxn, *vyn;
-    int32_t* faces;     // LDS copy or nullptr
-    float *xs, *ys, *red, *tot;
-    PoseCam* pc;
-};
-
-__device__ inline Lds carve(char* base, const LdsLayout& L) {
-    Lds s;
-    s.zbuf = (unsigned long long*)(base + L.zbuf);
-    s.vX = (float*)(base + L.vX); s.vY = (float*)(base + L.vY); s.vZ = (float*)(base + L.vZ);
-    s.vxn = (float*)(base + L.vxn); s.vyn = (float*)(base + L.vyn);
-    s.faces = L.faces >= 0 ? (int32_t*)(base + L.faces) : nullptr;
-    s.xs = (float*)(base + L.xs); s.ys = (float*)(base + L.ys);
-    s.red = (float*)(base + L.red); s.tot = (float*)(base + L.tot);
-    s.pc = (PoseCam*)(base + L.pc);
-    return s;
-}
-
-// One-time per-workgroup set-up: pixel-centre tables and the face list.
-__device__ inline void raster_prologue(const RasterCtx& rc, const Lds& s) {
-    const int H = rc.cc.H, W = rc.cc.W;
-    for (int i = threadIdx.x; i < W; i += blockDim.x) s.xs[i] = pix_to_ndc(W - 1 - i, W, H);
-    for (int i = threadIdx.x; i < H; i += blockDim.x) s.ys[i] = pix_to_ndc(H - 1 - i, H, W);
-    if (s.faces)
-        for (int i = threadIdx.x; i < rc.F * 3; i += blockDim.x) s.faces[i] = rc.faces[i];
-}
-
-__device__ inline void load_face(const RasterCtx& rc, const Lds& s, int f, int* i0, int* i1, int* i2) {
-    const int32_t* fp = s.faces ? s.faces : rc.faces;
-    *i0 = fp[3 * f + 0]; *i1 = fp[3 * f + 1]; *i2 = fp[3 * f + 2];
-}
-
-__device__ inline FaceVerts face_verts(const Lds& s, int i0, int i1, int i2) {
-    FaceVerts fv;
-    fv.x0 = s.vxn[i0]; fv.y0 = s.vyn[i0]; fv.z0 = s.vZ[i0];
-    fv.x1 = s.vxn[i1]; fv.y1 = s.vyn[i1]; fv.z1 = s.vZ[i1];
-    fv.x2 = s.vxn[i2]; fv.y2 = s.vyn[i2]; fv.z2 = s.vZ[i2];
-    return fv;
-}
-
-// Pose camera already in s.pc (and visible).  Clears the key buffer, projects every vertex and
-// rasterises every face.  On return (after the trailing barrier) s.zbuf holds, per pixel, the
-// (depth, face) key of the nearest covering face or kEmptyKey.
-__device__ inline void project_and_rasterize(const RasterCtx& rc, const Lds& s) {
-    const int HW = rc.cc.H * rc.cc.W;
-    for (int p = threadIdx.x; p < HW; p += blockDim.x) s.zbuf[p] = kEmptyKey;
-    {
-        float R[9], T[3];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = s.pc->R[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) T[i] = s.pc->T[i];
-        const float bx = s.pc->bx, by = s.pc->by;
-        for (int v = threadIdx.x; v < rc.V; v += blockDim.x) {
-            float Xv[3], xn, yn;
-            project_vertex(rc.cc, R, T, bx, by, rc.verts[3 * v], rc.verts[3 * v + 1], rc.verts[3 * v + 2], Xv, &xn, &yn);
-            s.vX[v] = Xv[0]; s.vY[v] = Xv[1]; s.vZ[v] = Xv[2];
-            s.vxn[v] = xn; s.vyn[v] = yn;
-        }
-    }
-    __syncthreads();
-    for (int f = threadIdx.x; f < rc.F; f += blockDim.x) {
-        int i0, i1, i2;
-        load_face(rc, s, f, &i0, &i1, &i2);
-        FaceVerts fv = face_verts(s, i0, i1, i2);
-        raster_face(f, fv, rc.cc.H, rc.cc.W, s.xs, s.ys, s.zbuf);
-    }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -352,6 +197,7 @@ struct RenderArgs {
     float* out_maps; int32_t* out_p2f; float* out_bary; float* out_zbuf;
 };
 
+template <bool FL>
 __global__ __launch_bounds__(kRasterThreads) void render_kernel(RenderArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
@@ -364,7 +210,8 @@ __global__ __launch_bounds__(kRasterThreads) void render_kernel(RenderArgs a) {
         pose_setup(a.rc.cc, C, a.theta[n], px, py, s.pc);
     }
     __syncthreads();
-    project_and_rasterize(a.rc, s);
+    project_vertices(a.rc, s);
+    raster_faces<FL>(a.rc, s);
     for (int p = threadIdx.x; p < HW; p += blockDim.x) {
         unsigned long long key = s.zbuf[p];
         int f = -1;
@@ -372,7 +219,7 @@ __global__ __launch_bounds__(kRasterThreads) void render_kernel(RenderArgs a) {
         int i0 = 0, i1 = 0, i2 = 0;
         if (key != kEmptyKey) {
             f = (int)(key & 0xFFFFFFFFull);
-            load_face(a.rc, s, f, &i0, &i1, &i2);
+            load_face<FL>(a.rc, s, f, &i0, &i1, &i2);
             FaceVerts fv = face_verts(s, i0, i1, i2);
             int yi = p / W, xi = p - yi * W;
             face_eval(fv, s.xs[xi], s.ys[yi], b, &pz);
@@ -418,8 +265,9 @@ extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* c
     a.memory_t = m->memory_t; a.C = m->C;
     a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
     a.out_maps = out_maps; a.out_p2f = out_p2f; a.out_bary = out_bary; a.out_zbuf = out_zbuf;
-    if (set_lds_limit(render_kernel, a.rc.L.total)) return NEMO_ERR_HIP;
-    hipLaunchKernelGGL(render_kernel, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    auto kern = a.rc.L.faces >= 0 ? render_kernel<true> : render_kernel<false>;
+    if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }
@@ -436,31 +284,32 @@ struct RenderBwdArgs {
     float* g_campos; float* g_theta; float* g_principal;
 };
 
+template <bool FL>
 __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
     const int n = blockIdx.x;
     const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
     raster_prologue(a.rc, s);
-    PoseCam pc_local;
     if (threadIdx.x == 0) {
         float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
         float px = a.principal ? a.principal[2 * n] : a.def_px, py = a.principal ? a.principal[2 * n + 1] : a.def_py;
-        pose_setup(a.rc.cc, C, a.theta[n], px, py, &pc_local);
-        *s.pc = pc_local;
+        pose_setup(a.rc.cc, C, a.theta[n], px, py, s.pc);
     }
     __syncthreads();
-    project_and_rasterize(a.rc, s);
+    project_vertices(a.rc, s);
+    raster_faces<FL>(a.rc, s);
+    unsigned int* seg;
+    const int cnt = compact_covered(a.rc, s, &seg);
     PixelGrad acc;
     for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
     acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
-    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-        unsigned long long key = s.zbuf[p];
-        if (key == kEmptyKey) continue;
-        int f = (int)(key & 0xFFFFFFFFull), i0, i1, i2;
-        load_face(a.rc, s, f, &i0, &i1, &i2);
+    for (int i = threadIdx.x & 63; i < cnt; i += 64) {
+        int xi, yi, f, i0, i1, i2;
+        unpack_entry(seg[i], &xi, &yi, &f);
+        const int p = yi * W + xi;
+        load_face<FL>(a.rc, s, f, &i0, &i1, &i2);
         FaceVerts fv = face_verts(s, i0, i1, i2);
-        int yi = p / W, xi = p - yi * W;
         float gb[3] = {0.f, 0.f, 0.f};
         const float* gm = a.grad_maps + (size_t)n * a.C * HW + p;
         for (int c = 0; c < a.C; ++c) {
@@ -478,7 +327,7 @@ __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderB
     block_sum<14>(vals, s.red, s.tot);
     if (threadIdx.x == 0) {
         float gC[3], gth, gpx, gpy;
-        pose_backward(a.rc.cc, pc_local, s.tot, s.tot + 9, s.tot[12], s.tot[13], gC, &gth, &gpx, &gpy);
+        pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], gC, &gth, &gpx, &gpy);
         if (a.g_campos) { a.g_campos[3 * n] = gC[0]; a.g_campos[3 * n + 1] = gC[1]; a.g_campos[3 * n + 2] = gC[2]; }
         if (a.g_theta) a.g_theta[n] = gth;
         if (a.g_principal) { a.g_principal[2 * n] = gpx; a.g_principal[2 * n + 1] = gpy; }
@@ -500,8 +349,9 @@ extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const
     a.memory_t = m->memory_t; a.C = m->C;
     a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
     a.grad_maps = grad_maps; a.g_campos = g_campos; a.g_theta = g_theta; a.g_principal = g_principal;
-    if (set_lds_limit(render_backward_kernel, a.rc.L.total)) return NEMO_ERR_HIP;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    auto kern = a.rc.L.faces >= 0 ? render_backward_kernel<true> : render_backward_kernel<false>;
+    if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }
@@ -707,10 +557,16 @@ extern "C" int nemo_vertex_similarity(nemo_mesh_t m, const float* table, const f
 // ------------------------------------------------------------------------------------------
 // pose optimisation
 // ------------------------------------------------------------------------------------------
+#ifdef NEMO_STAMPS
+#define STAMP(i) do { __syncthreads(); if (tid == 0) { long long t_ = clock64(); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 struct OptState {
     float P[6], m[6], v[6];
     double lr, b1p, b2p;
-    float sum_clu, first_loss, last_loss;
+    float first_loss, last_loss;
 };
 
 struct SolveArgs {
@@ -724,6 +580,7 @@ struct SolveArgs {
     float* out_pose; float* out_hist;
 };
 
+template <bool FL>
 __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
@@ -735,7 +592,7 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
     raster_prologue(a.rc, s);
 
     // optimiser state lives in LDS; only thread 0 touches it
-    OptState* os = (OptState*)(smem + a.rc.L.opt);
+    OptState* os = (OptState*)s.opt;
     const int np = a.dof == 6 ? 6 : 4;
     if (tid == 0) {
         for (int k = 0; k < 6; ++k) { os->m[k] = 0.0f; os->v[k] = 0.0f; }
@@ -744,58 +601,91 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         os->P[4] = a.init_principal ? a.init_principal[2 * h] : a.def_px;
         os->P[5] = a.init_principal ? a.init_principal[2 * h + 1] : a.def_py;
         os->lr = a.lr; os->b1p = 1.0; os->b2p = 1.0;
-        os->sum_clu = 0.0f; os->first_loss = 0.0f; os->last_loss = 0.0f;
+        os->first_loss = 0.0f; os->last_loss = 0.0f;
+    }
+    // per-image constants of the loss: sum_p max(0, clu) (what an uncovered image scores) and sum_p clu
+    float base_max, base_clu;
+    {
+        float v2[2] = {0.0f, 0.0f};
+        for (int p = tid; p < HW; p += blockDim.x) { float cl = clu[p]; v2[0] += fmaxf(0.0f, cl); v2[1] += cl; }
+        block_sum<2>(v2, s.red, s.tot);
+        base_max = s.tot[0]; base_clu = s.tot[1];
     }
     const float fHW = (float)HW;
+#ifdef NEMO_STAMPS
+    long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_t = clock64();
+#endif
 
     for (int step = 0; step < a.steps; ++step) {
         if (tid == 0) pose_setup(a.rc.cc, os->P, os->P[3], os->P[4], os->P[5], s.pc);
         __syncthreads();
-        project_and_rasterize(a.rc, s);
+        STAMP(0);
+        project_vertices(a.rc, s);
+        STAMP(1);
+        raster_pass1<FL>(a.rc, s);
+        STAMP(7);
+        raster_pass2<FL>(a.rc, s);
+        STAMP(2);
+        unsigned int* seg;
+        const int cnt = compact_covered(a.rc, s, &seg);
+        STAMP(3);
 
-        float vals[16];
+        float vals[15];
         {
             PixelGrad acc;
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
             acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
-            float smax = 0.0f, sclu = 0.0f;
-            for (int p = tid; p < HW; p += blockDim.x) {
-                const unsigned long long key = s.zbuf[p];
-                const float cl = clu[p];
-                float obj = 0.0f;
-                if (key != kEmptyKey) {
-                    int f = (int)(key & 0xFFFFFFFFull), i0, i1, i2;
-                    load_face(a.rc, s, f, &i0, &i1, &i2);
-                    float d0 = tab[(size_t)i0 * HW + p], d1 = tab[(size_t)i1 * HW + p], d2 = tab[(size_t)i2 * HW + p];
-                    FaceVerts fv = face_verts(s, i0, i1, i2);
-                    int yi = p / W, xi = p - yi * W;
-                    float xf = s.xs[xi], yf = s.ys[yi];
-                    float b[3], pz;
-                    face_eval(fv, xf, yf, b, &pz);
-                    obj = (b[0] * d0 + b[1] * d1) + b[2] * d2;
-                    float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-                    if (mk != 0.0f) {
-                        float g = -mk * a.inv_norm;
-                        float gb[3] = {g * d0, g * d1, g * d2};
-                        float X0[3] = {s.vX[i0], s.vY[i0], s.vZ[i0]}, X1[3] = {s.vX[i1], s.vY[i1], s.vZ[i1]},
-                              X2[3] = {s.vX[i2], s.vY[i2], s.vZ[i2]};
-                        pixel_backward(a.rc.cc, fv, X0, X1, X2, xf, yf, gb, &acc);
-                    }
+            float dmax = 0.0f;      // sum over covered pixels of max(obj, clu) - max(0, clu)
+            // The covered entries of this wave, four per lane at a time: all table / clutter loads of a
+            // batch are issued before any of them is used, so one memory round trip covers the batch.
+            constexpr int UNR = 2;
+            for (int ib = tid & 63; ib < cnt; ib += 64 * UNR) {
+                int px[UNR], py[UNR], vi[UNR][3];
+                float dd[UNR][3], cc_[UNR];
+                bool ok[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int idx = ib + u * 64;
+                    ok[u] = idx < cnt;
+                    int f;
+                    unpack_entry(ok[u] ? seg[idx] : 0u, &px[u], &py[u], &f);
+                    load_face<FL>(a.rc, s, f, &vi[u][0], &vi[u][1], &vi[u][2]);
                 }
-                smax += fmaxf(obj, cl);
-                sclu += cl;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int p = py[u] * W + px[u];
+                    if (ok[u]) {
+                        dd[u][0] = tab[(size_t)vi[u][0] * HW + p];
+                        dd[u][1] = tab[(size_t)vi[u][1] * HW + p];
+                        dd[u][2] = tab[(size_t)vi[u][2] * HW + p];
+                        cc_[u] = clu[p];
+                    } else { dd[u][0] = dd[u][1] = dd[u][2] = 0.0f; cc_[u] = 0.0f; }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (!ok[u]) continue;
+                    const int i0 = vi[u][0], i1 = vi[u][1], i2 = vi[u][2];
+                    FaceVerts fv = face_verts(s, i0, i1, i2);
+                    const float X0[3] = {s.vX[i0], s.vY[i0], fv.z0}, X1[3] = {s.vX[i1], s.vY[i1], fv.z1},
+                                X2[3] = {s.vX[i2], s.vY[i2], fv.z2};
+                    const float obj = pixel_score_and_grad(a.rc.cc, fv, X0, X1, X2, s.xs[px[u]], s.ys[py[u]], dd[u], cc_[u],
+                                                           a.inv_norm, &acc);
+                    dmax += fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 9; ++i) vals[i] = acc.M[i];
             vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2];
-            vals[12] = acc.gbx; vals[13] = acc.gby; vals[14] = smax; vals[15] = sclu;
+            vals[12] = acc.gbx; vals[13] = acc.gby; vals[14] = dmax;
         }
-        block_sum<16>(vals, s.red, s.tot);
+        STAMP(4);
+        block_sum<15>(vals, s.red, s.tot);
+        STAMP(5);
 
         if (tid == 0) {
-            if (step == 0) os->sum_clu = s.tot[15];
-            float loss = 1.0f - (s.tot[14] / fHW - os->sum_clu / fHW);
+            float loss = 1.0f - ((base_max + s.tot[14]) / fHW - base_clu / fHW);
             if (step == 0) os->first_loss = loss;
             os->last_loss = loss;
             if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
@@ -820,12 +710,16 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
             }
             if (a.lr_every > 0 && (step + 1) % a.lr_every == 0) os->lr *= a.gamma;
         }
-        // the next iteration's first barrier orders these LDS accesses before s.tot / s.pc / s.zbuf are reused
+        STAMP(6);
+        // the next iteration's first barrier orders these LDS accesses before s.tot / s.pc are reused
     }
     if (tid == 0) {
         float* o = a.out_pose + (size_t)h * 8;
         for (int k = 0; k < 6; ++k) o[k] = os->P[k];
         o[6] = os->last_loss; o[7] = os->first_loss;
+#ifdef NEMO_STAMPS
+        if (a.out_hist) for (int k = 0; k < 8; ++k) a.out_hist[(size_t)h * a.steps + k] = (float)stamp_acc[k] / (float)a.steps;
+#endif
     }
 }
 
@@ -854,8 +748,9 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     a.steps = opt->steps; a.lr_every = opt->lr_every;
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
     a.out_pose = out_pose; a.out_hist = out_hist;
-    if (set_lds_limit(solve_kernel, a.rc.L.total)) return NEMO_ERR_HIP;
-    hipLaunchKernelGGL(solve_kernel, dim3(n_hyp), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    auto kern = a.rc.L.faces >= 0 ? solve_kernel<true> : solve_kernel<false>;
+    if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

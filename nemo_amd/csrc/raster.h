@@ -1,0 +1,391 @@
+// Workgroup-level rasteriser front end shared by the solve / render / render-backward kernels.
+// One workgroup (16 waves) owns one camera pose; everything lives in LDS.  The kernels are bound by
+// vector-instruction issue, so the structure is about executing as few wave-instructions as possible:
+//
+//   project_vertices   every vertex -> view coordinates + NDC xy (5 floats, struct of arrays)
+//   raster_pass1       one face per lane, registers only.  A conservative bounding box, then a cheap
+//                      conservative edge-sign test (fma arithmetic with an error margin) over its pixels;
+//                      survivors are recorded in a 64-bit mask.  The wave reserves queue space with one
+//                      DPP scan + one LDS atomic per class and the lanes write (face, pixel) pairs: faces
+//                      nearer than the object centre go to the near half of the queue, the rest to the
+//                      far half.
+//   raster_pass2       the queue is consumed densely, one pair per lane: exact bounding-box test, exact
+//                      barycentrics and depth, 64-bit LDS atomic min on (depth bits << 32 | face).  The far
+//                      half runs after the near half and skips a pair whose face cannot beat the depth
+//                      already stored (its smallest vertex depth is larger): for a closed mesh that removes
+//                      almost all back-face evaluations.  Every decision that can change the winner uses
+//                      the exact arithmetic of geom.h, so the result equals a serial scan over the faces.
+//   compact_covered    each wave scans its own interleaved 64-pixel chunks of the key buffer, resets
+//                      them for the next step and compacts the covered (face, pixel) entries into its
+//                      own segment: the pixel work that follows runs on dense lanes, and because a wave
+//                      only ever reads its own segment in a fixed order every float sum is reproducible.
+#pragma once
+#include "geom.h"
+
+#pragma clang fp contract(off)
+
+namespace nemo {
+
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kRasterThreads = 1024;
+constexpr int kRasterWaves = kRasterThreads / 64;
+constexpr int kMaxSide = 128;                // queue entry = xi | yi << 7 | face << 14
+constexpr int kPixBits = 14;
+constexpr int kMaxFaces = 1 << (32 - kPixBits);
+
+__device__ inline unsigned int pack_entry(int xi, int yi, int f) {
+    return (unsigned)xi | ((unsigned)yi << 7) | ((unsigned)f << kPixBits);
+}
+__device__ inline void unpack_entry(unsigned int e, int* xi, int* yi, int* f) {
+    *xi = e & 127; *yi = (e >> 7) & 127; *f = e >> kPixBits;
+}
+
+struct LdsLayout {
+    int zbuf;                   // u64 [HW]
+    int vX, vY, vZ, vxn, vyn;   // f32 [V] each
+    int faces;                  // i32 [F*3] (or -1: faces are read from global memory)
+    int xs, ys;                 // f32 [W], [H]: NDC centre of pixel column xi / row yi
+    int queue;                  // u32 [qcap]: pair queue, later the per-wave covered segments
+    int qcap;                   // entries
+    int seg;                    // entries per wave segment (multiple of 64)
+    int red;                    // f32 [16 values][16 waves]
+    int tot;                    // f32 [16]
+    int pc;                     // PoseCam
+    int opt;                    // optimiser state (solve kernel) + queue counter
+    int total;
+};
+
+inline int align16(int x) { return (x + 15) & ~15; }
+
+inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
+    LdsLayout L;
+    const int HW = H * W;
+    int o = 0;
+    L.zbuf = o; o = align16(o + 8 * HW);
+    L.vX = o; o = align16(o + 4 * V);
+    L.vY = o; o = align16(o + 4 * V);
+    L.vZ = o; o = align16(o + 4 * V);
+    L.vxn = o; o = align16(o + 4 * V);
+    L.vyn = o; o = align16(o + 4 * V);
+    if (faces_in_lds) { L.faces = o; o = align16(o + 12 * F); } else L.faces = -1;
+    L.xs = o; o = align16(o + 4 * W);
+    L.ys = o; o = align16(o + 4 * H);
+    const int chunks = (HW + 63) / 64;
+    L.seg = ((chunks + kRasterWaves - 1) / kRasterWaves) * 64;
+    L.qcap = L.seg * kRasterWaves;
+    if (L.qcap < 8192) L.qcap = 8192;
+    L.queue = o; o = align16(o + 4 * L.qcap);
+    L.red = o; o = align16(o + 4 * 16 * kRasterWaves);
+    L.tot = o; o = align16(o + 4 * 16);
+    L.pc = o; o = align16(o + (int)sizeof(PoseCam));
+    L.opt = o; o = align16(o + 256);
+    L.total = o;
+    return L;
+}
+
+struct RasterCtx {
+    const float* verts;
+    const int32_t* faces;
+    int V, F;
+    CamConst cc;
+    LdsLayout L;
+};
+
+struct Lds {
+    unsigned long long* zbuf;
+    float *vX, *vY, *vZ, *vxn, *vyn;
+    int32_t* faces;     // LDS copy or nullptr
+    float *xs, *ys, *red, *tot;
+    unsigned int* queue;
+    unsigned int* qcount;    // [2]: pairs in the near half, pairs in the far half
+    PoseCam* pc;
+    char* opt;
+};
+
+__device__ inline Lds carve(char* base, const LdsLayout& L) {
+    Lds s;
+    s.zbuf = (unsigned long long*)(base + L.zbuf);
+    s.vX = (float*)(base + L.vX); s.vY = (float*)(base + L.vY); s.vZ = (float*)(base + L.vZ);
+    s.vxn = (float*)(base + L.vxn); s.vyn = (float*)(base + L.vyn);
+    s.faces = L.faces >= 0 ? (int32_t*)(base + L.faces) : nullptr;
+    s.xs = (float*)(base + L.xs); s.ys = (float*)(base + L.ys);
+    s.red = (float*)(base + L.red); s.tot = (float*)(base + L.tot);
+    s.queue = (unsigned int*)(base + L.queue);
+    s.pc = (PoseCam*)(base + L.pc);
+    s.opt = base + L.opt;
+    s.qcount = (unsigned int*)(base + L.opt + 240);
+    return s;
+}
+
+// ---- reductions (fixed order => bitwise reproducible) ------------------------------------------
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+
+// Sum within each row of 16 lanes; every lane of the row returns the row total.
+__device__ inline float row16_sum(float v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    return v;
+}
+
+// Sum over the 64 lanes of a wave; every lane returns the total.
+__device__ inline float wave_sum(float v) {
+    v = row16_sum(v);
+    float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
+
+// Block total of NV (<= 16) values per thread for a 16-wave workgroup.  red: LDS [NV][16], tot: LDS [NV].
+// After the call tot[k] holds the total, visible to every thread.
+template <int NV>
+__device__ inline void block_sum(const float* vals, float* red, float* tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float sv = wave_sum(vals[k]);
+        if (lane == 0) red[k * kRasterWaves + wave] = sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV * kRasterWaves) {      // one 16-lane row per value: lanes = the 16 waves' partials
+        float sv = row16_sum(red[threadIdx.x]);
+        if ((threadIdx.x & 15) == 0) tot[threadIdx.x >> 4] = sv;
+    }
+    __syncthreads();
+}
+
+// ---- front end ------------------------------------------------------------------------------------
+// One-time per-workgroup set-up: pixel-centre tables, the face list, an empty key buffer.
+__device__ inline void raster_prologue(const RasterCtx& rc, const Lds& s) {
+    const int H = rc.cc.H, W = rc.cc.W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) s.xs[i] = pix_to_ndc(W - 1 - i, W, H);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s.ys[i] = pix_to_ndc(H - 1 - i, H, W);
+    if (s.faces)
+        for (int i = threadIdx.x; i < rc.F * 3; i += blockDim.x) s.faces[i] = rc.faces[i];
+    for (int p = threadIdx.x; p < H * W; p += blockDim.x) s.zbuf[p] = kEmptyKey;
+    if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
+}
+
+template <bool FACES_LDS>
+__device__ inline void load_face(const RasterCtx& rc, const Lds& s, int f, int* i0, int* i1, int* i2) {
+    if (FACES_LDS) { *i0 = s.faces[3 * f + 0]; *i1 = s.faces[3 * f + 1]; *i2 = s.faces[3 * f + 2]; }
+    else { *i0 = rc.faces[3 * f + 0]; *i1 = rc.faces[3 * f + 1]; *i2 = rc.faces[3 * f + 2]; }
+}
+
+__device__ inline FaceVerts face_verts(const Lds& s, int i0, int i1, int i2) {
+    FaceVerts fv;
+    fv.x0 = s.vxn[i0]; fv.y0 = s.vyn[i0]; fv.z0 = s.vZ[i0];
+    fv.x1 = s.vxn[i1]; fv.y1 = s.vyn[i1]; fv.z1 = s.vZ[i1];
+    fv.x2 = s.vxn[i2]; fv.y2 = s.vyn[i2]; fv.z2 = s.vZ[i2];
+    return fv;
+}
+
+// Pose camera in s.pc must be visible (barrier before).  Ends with a barrier.
+__device__ inline void project_vertices(const RasterCtx& rc, const Lds& s) {
+    float R[9], T[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = s.pc->R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = s.pc->T[i];
+    const float bx = s.pc->bx, by = s.pc->by;
+    for (int v = threadIdx.x; v < rc.V; v += blockDim.x) {
+        float Xv[3], xn, yn;
+        project_vertex(rc.cc, R, T, bx, by, rc.verts[3 * v], rc.verts[3 * v + 1], rc.verts[3 * v + 2], Xv, &xn, &yn);
+        s.vX[v] = Xv[0]; s.vY[v] = Xv[1]; s.vZ[v] = Xv[2];
+        s.vxn[v] = xn; s.vyn[v] = yn;
+    }
+    __syncthreads();
+}
+
+// Inclusive prefix sum of one int per lane over the wave (DPP within 16-lane rows, row totals via readlane).
+template <int CTRL>
+__device__ inline int dpp_shr_add(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ inline int wave_inclusive_scan(int v, int* total) {
+    v = dpp_shr_add<0x111>(v);   // row_shr:1
+    v = dpp_shr_add<0x112>(v);   // row_shr:2
+    v = dpp_shr_add<0x114>(v);   // row_shr:4
+    v = dpp_shr_add<0x118>(v);   // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31),
+              r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+    const int row = (threadIdx.x & 63) >> 4;
+    v += row == 0 ? 0 : (row == 1 ? r0 : (row == 2 ? r0 + r1 : r0 + r1 + r2));
+    *total = r0 + r1 + r2 + r3;
+    return v;
+}
+
+// Exact coverage test of one (face, pixel) pair and depth-buffer update.
+__device__ inline void eval_pair(int face, const FaceVerts& fv, int xi, int yi, int W, const Lds& s) {
+    const float xf = s.xs[xi], yf = s.ys[yi];
+    const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
+    const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
+    if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) return;     // exact bounding-box rejection
+    eval_and_min(face, fv, yi * W + xi, xf, yf, s.zbuf);
+}
+
+// Key buffer must be empty and s.qcount[0..1] == 0 on entry; ends with a barrier.
+template <bool FACES_LDS>
+__device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
+    const int H = rc.cc.H, W = rc.cc.W;
+    const int half = rc.L.qcap >> 1;
+    // approximate pixel centres: x(j) = x_org + j * dx in the flipped index j (error of a few ulp of the
+    // extent, covered by the margin of the conservative tests)
+    const float rx = ndc_range(W, H), ry = ndc_range(H, W);
+    const float dx = rx / (float)W, dy = ry / (float)H;
+    const float x_org = -0.5f * rx + 0.5f * dx, y_org = -0.5f * ry + 0.5f * dy;
+    const float inv_dx = (float)W / rx, inv_dy = (float)H / ry;
+    const float z_mid3 = 3.0f * s.pc->T[2];          // three times the view depth of the object origin
+    for (int base = 0; base < rc.F; base += blockDim.x) {
+        const int f = base + threadIdx.x;
+        FaceVerts fv = {};
+        bool ok = false, zpos = false, near = false;
+        int jx0 = 0, jy0 = 0, nx = 0, ny = 0;
+        float A0 = 0, B0 = 0, C0 = 0, A1 = 0, B1 = 0, C1 = 0, A2 = 0, B2 = 0, C2 = 0, tol = 0;
+        if (f < rc.F) {
+            int i0, i1, i2;
+            load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+            fv = face_verts(s, i0, i1, i2);
+            const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2);
+            const float farea = edge_fn(fv.x0, fv.y0, fv.x1, fv.y1, fv.x2, fv.y2);
+            ok = !(zmax < kEps) && !(farea <= kEps && farea >= -kEps) && (farea == farea);
+            const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
+            const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
+            // conservative pixel range (flipped indices); 1e-3 pixel of slack, the exact test is in pass 2
+            const float tx0 = (xmin - x_org) * inv_dx - 1e-3f, tx1 = (xmax - x_org) * inv_dx + 1e-3f;
+            const float ty0 = (ymin - y_org) * inv_dy - 1e-3f, ty1 = (ymax - y_org) * inv_dy + 1e-3f;
+            ok = ok && !(tx1 < 0.0f) && !(ty1 < 0.0f) && !(tx0 > (float)(W - 1)) && !(ty0 > (float)(H - 1));
+            jx0 = clamp_index(ceilf(tx0), W, 0); jy0 = clamp_index(ceilf(ty0), H, 0);
+            const int jx1 = clamp_index(floorf(tx1), W, W - 1), jy1 = clamp_index(floorf(ty1), H, H - 1);
+            nx = jx1 - jx0 + 1; ny = jy1 - jy0 + 1;
+            ok = ok && nx > 0 && ny > 0;
+            zpos = fv.z0 > 0.0f && fv.z1 > 0.0f && fv.z2 > 0.0f;
+            near = (fv.z0 + fv.z1) + fv.z2 < z_mid3;
+            // edge functions as planes e_i(x,y) = A_i x + B_i y + C_i, oriented so that inside means >= 0
+            const float sgn = farea < 0.0f ? -1.0f : 1.0f;
+            A0 = sgn * (fv.y2 - fv.y1); B0 = -sgn * (fv.x2 - fv.x1); C0 = -(A0 * fv.x1 + B0 * fv.y1);
+            A1 = sgn * (fv.y0 - fv.y2); B1 = -sgn * (fv.x0 - fv.x2); C1 = -(A1 * fv.x2 + B1 * fv.y2);
+            A2 = sgn * (fv.y1 - fv.y0); B2 = -sgn * (fv.x1 - fv.x0); C2 = -(A2 * fv.x0 + B2 * fv.y0);
+            const float ext = fmaxf(xmax - xmin, ymax - ymin);
+            const float mag = fmaxf(fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax))), 1.5f);
+            tol = 2e-5f * ext * mag;      // >> the rounding error of either evaluation (a few 1e-7 * ext * mag)
+            if (!(tol == tol) || !zpos) tol = __builtin_inff();   // odd geometry: keep every pixel of the box
+        }
+        unsigned long long mask = 0;
+        int cnt_near = 0, cnt_far = 0;
+        if (ok) {
+            if (nx <= 8 && ny <= 8) {
+                for (int r = 0; r < ny; ++r) {
+                    const float yf = __builtin_fmaf((float)(jy0 + r), dy, y_org);
+                    const float r0 = __builtin_fmaf(B0, yf, C0), r1 = __builtin_fmaf(B1, yf, C1), r2 = __builtin_fmaf(B2, yf, C2);
+                    for (int c = 0; c < nx; ++c) {
+                        const float xf = __builtin_fmaf((float)(jx0 + c), dx, x_org);
+                        const float e0 = __builtin_fmaf(A0, xf, r0), e1 = __builtin_fmaf(A1, xf, r1), e2 = __builtin_fmaf(A2, xf, r2);
+                        if (!(fminf(fminf(e0, e1), e2) < -tol)) mask |= 1ull << (r * 8 + c);
+                    }
+                }
+                const int n = __popcll(mask);
+                cnt_near = near ? n : 0;
+                cnt_far = near ? 0 : n;
+            } else {
+                // close-up face: evaluate its box in place (exact path), no queueing
+                for (int jy = jy0; jy < jy0 + ny; ++jy)
+                    for (int jx = jx0; jx < jx0 + nx; ++jx) eval_pair(f, fv, W - 1 - jx, H - 1 - jy, W, s);
+            }
+        }
+        int total;
+        const int incl = wave_inclusive_scan(cnt_near | (cnt_far << 16), &total);
+        if (total) {
+            unsigned int bn = 0, bf = 0;
+            if ((threadIdx.x & 63) == 0) {
+                if (total & 0xFFFF) bn = atomicAdd(&s.qcount[0], (unsigned)(total & 0xFFFF));
+                if (total >> 16) bf = atomicAdd(&s.qcount[1], (unsigned)(total >> 16));
+            }
+            bn = __builtin_amdgcn_readfirstlane(bn);
+            bf = __builtin_amdgcn_readfirstlane(bf);
+            const int excl = incl - (cnt_near | (cnt_far << 16));
+            unsigned int slot = near ? bn + (unsigned)(excl & 0xFFFF) : bf + (unsigned)(excl >> 16);
+            const int off = near ? 0 : half;
+            while (mask) {
+                const int k = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int xi = W - 1 - (jx0 + (k & 7)), yi = H - 1 - (jy0 + (k >> 3));
+                if (slot < (unsigned)half) s.queue[off + slot] = pack_entry(xi, yi, f);
+                else eval_pair(f, fv, xi, yi, W, s);          // queue half full: evaluate in place
+                ++slot;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Ends with a barrier and with both queue counters reset.
+template <bool FACES_LDS>
+__device__ inline void raster_pass2(const RasterCtx& rc, const Lds& s) {
+    const int W = rc.cc.W;
+    const int half = rc.L.qcap >> 1;
+    const int n_near = min((int)s.qcount[0], half), n_far = min((int)s.qcount[1], half);
+    for (int i = threadIdx.x; i < n_near; i += blockDim.x) {
+        int xi, yi, f, i0, i1, i2;
+        unpack_entry(s.queue[i], &xi, &yi, &f);
+        load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+        eval_pair(f, face_verts(s, i0, i1, i2), xi, yi, W, s);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_far; i += blockDim.x) {
+        int xi, yi, f, i0, i1, i2;
+        unpack_entry(s.queue[half + i], &xi, &yi, &f);
+        load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+        const unsigned long long cur = s.zbuf[yi * W + xi];
+        const FaceVerts fv = face_verts(s, i0, i1, i2);
+        // the interpolated depth of a covered pixel is >= zmin * (1 - 5e-7): a face whose nearest vertex
+        // is clearly behind the stored depth cannot win this pixel
+        const float zmin = fminf(fminf(fv.z0, fv.z1), fv.z2);
+        if (cur != kEmptyKey && zmin * 0.999999f > __uint_as_float((unsigned)(cur >> 32))) continue;
+        eval_pair(f, fv, xi, yi, W, s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
+}
+
+template <bool FACES_LDS>
+__device__ inline void raster_faces(const RasterCtx& rc, const Lds& s) {
+    raster_pass1<FACES_LDS>(rc, s);
+    raster_pass2<FACES_LDS>(rc, s);
+}
+
+// Each wave compacts the covered pixels of its own chunks (chunk c = 64 consecutive pixels, owned by
+// wave c % 16) into its segment of the queue area and resets the key buffer.  Returns the number of
+// entries in this wave's segment (pack_entry format).  Ends with a barrier.
+__device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigned int** seg_out) {
+    const int HW = rc.cc.H * rc.cc.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int* seg = s.queue + wave * rc.L.seg;
+    int count = 0;
+    for (int c = wave; c * 64 < HW; c += kRasterWaves) {
+        const int p = c * 64 + lane;
+        unsigned long long key = kEmptyKey;
+        if (p < HW) key = s.zbuf[p];
+        const bool cov = key != kEmptyKey;
+        if (cov) s.zbuf[p] = kEmptyKey;
+        const unsigned long long m = __ballot(cov);
+        if (cov) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            const int yi = p / rc.cc.W;
+            seg[count + rank] = pack_entry(p - yi * rc.cc.W, yi, (int)(key & 0xFFFFFFFFull));
+        }
+        count += __popcll(m);
+    }
+    __syncthreads();
+    *seg_out = seg;
+    return count;
+}
+
+}  // namespace nemo

@@ -1,0 +1,129 @@
+"""Generates the committed fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY.
+
+    python oracle/gen_golden.py [leaf] [small] [full]
+
+leaf   tests/golden/leaf_golden.npz   - outputs of the reference's OWN dependency-free leaf files
+       (nemo/utils/general.py, pose.py, features.py, flow_warp.py), loaded standalone from
+       /root/reference with importlib (their package __init__ cannot be imported: it pulls in
+       pytorch3d / BboxTools / cv2).  These pin the oracle's leaf functions to the reference.
+small  tests/golden/oracle_small.npz  - oracle outputs on a 40x50x32 scene (face-index buffers of the
+       144-pose grid, grid losses, a 300-step solve).
+full   tests/golden/oracle_full.npz   - oracle outputs at BASELINE size (80x100x128, V=1118, F=1904):
+       face-index buffers of 8 poses, one image's grid losses, a 2-image 300-step solve.
+
+The render-path fixtures come from the oracle itself (parity with PyTorch3D is unpinned: no PyTorch3D
+here); they freeze the oracle so that a change in its behaviour, or a difference between machines, is
+detected, and give the GPU tests full-size expected values without re-running minutes of CPU work.
+Only inputs and expected outputs are stored - no source text.
+"""
+import importlib.util
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refsolver as R          # noqa: E402
+from tests.common import GRID_CFG, Scene, random_poses   # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def _load(rel):
+    spec = importlib.util.spec_from_file_location("ref_" + os.path.basename(rel)[:-3], os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _Node(dict):
+    def __getattr__(self, k):
+        v = self[k]
+        return _Node(v) if isinstance(v, dict) else v
+
+
+CFG6D = dict(GRID_CFG, dist_sample=dict(min=3.0, max=9.0, num=4), px_sample=dict(min=0.25, max=0.75, num=5),
+             py_sample=dict(min=0.25, max=0.75, num=5))
+
+
+def gen_leaf():
+    general = _load("nemo/utils/general.py")
+    pose = _load("nemo/utils/pose.py")
+    features = _load("nemo/utils/features.py")
+    flow = _load("nemo/utils/flow_warp.py")
+    out = {}
+    for name, cfg in (("3d", GRID_CFG), ("6d", CFG6D)):
+        for k, arr in zip(("azim", "elev", "theta", "dist", "px", "py"), general.get_param_samples(_Node(inference=cfg))):
+            out[f"grid_{name}_{k}"] = np.asarray(arr)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(4, 3, generator=g), torch.randn(4, 3, generator=g)
+    out["lin_start"], out["lin_end"] = a.numpy(), b.numpy()
+    out["lin_out"] = general.tensor_linspace(a, b, 7).numpy()
+    angles = np.array([[0.1, 0.2, 0.3], [-0.4, 1.0, 5.0], [0.0, 0.0, 0.0], [0.5, -0.5, 3.0]])
+    out["rot_in"] = angles
+    out["rot_out"] = np.stack([pose.cal_rotation_matrix(t, e, a_, 5.0) for t, e, a_ in angles])
+    x = torch.randn(2560, 16, generator=g)
+    out["norm_in"] = x.numpy()
+    out["norm_out"] = features.normalize_features(torch.mean(x, dim=0)).numpy()
+    im, fl = torch.randn(2, 3, 6, 7, generator=g), torch.randn(2, 2, 6, 7, generator=g)
+    out["warp_im"], out["warp_flow"] = im.numpy(), fl.numpy()
+    out["warp_out"] = flow.flow_warp(im, fl).numpy()
+    np.savez_compressed(os.path.join(GOLD, "leaf_golden.npz"), **out)
+    print("leaf_golden.npz:", {k: v.shape for k, v in out.items()})
+
+
+def _solve_fixture(sc, B, epochs, first_seed):
+    fm, gts = sc.feature_maps(B, first_seed)
+    clu = R.clutter_score(fm, sc.clutter)
+    g = torch.Generator().manual_seed(77 + first_seed)
+    az = torch.tensor([t["azimuth"] for t in gts]) + 0.25 * (torch.rand(B, generator=g) - 0.5)
+    el = torch.tensor([t["elevation"] for t in gts]) + 0.2 * (torch.rand(B, generator=g) - 0.5)
+    th0 = (torch.tensor([t["theta"] for t in gts]) + 0.2 * (torch.rand(B, generator=g) - 0.5)).float()
+    C0 = R.camera_position_from_spherical_angles(5.0, el, az)
+    Cr, thr, _, scores, hist = R.optimize_poses(sc.ref, fm, clu, C0, th0, None, 3, epochs=epochs, record=True)
+    return dict(first_seed=np.int64(first_seed), C0=C0.numpy(), th0=th0.numpy(), C=Cr.numpy(), theta=thr.numpy(),
+                scores=scores.numpy(), loss_hist=torch.stack([h["per_image"] for h in hist], dim=1).numpy(),
+                grad_C0=hist[0]["grad_C"].numpy(), grad_theta0=hist[0]["grad_theta"].numpy(), clutter_map=clu.numpy())
+
+
+def gen_small():
+    sc = Scene(40, 50, 32, 150, 375.0 / 2)
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = R.get_pre_render_samples(sc.ref, az, el, th, di)
+    p2f, _, _ = R.fragments(sc.ref.verts, sc.ref.faces, cs, ths, sc.cam)
+    fm, _ = sc.feature_maps(5)
+    clu = R.clutter_score(fm, sc.clutter)
+    loss = R.grid_losses(maps, fm, clu).T
+    out = dict(grid_campos=cs.numpy(), grid_theta=ths.numpy(), grid_p2f=p2f.numpy().astype(np.int16),
+               grid_loss=loss.numpy(), grid_argmin=loss.argmin(dim=1).numpy(),
+               map_checksum=maps.double().sum(dim=(1, 2, 3, 4)).numpy())
+    out.update({"solve_" + k: v for k, v in _solve_fixture(sc, 4, 300, 0).items()})
+    np.savez_compressed(os.path.join(GOLD, "oracle_small.npz"), **out)
+    print("oracle_small.npz written")
+
+
+def gen_full():
+    sc = Scene(80, 100, 128, 1000, 375.0, n_clutter=2560)
+    campos, theta = random_poses(8, seed=11, dist=(3.0, 7.0))
+    p2f, bary, zbuf = R.fragments(sc.ref.verts, sc.ref.faces, campos, theta, sc.cam)
+    out = dict(campos=campos.numpy(), theta=theta.numpy(), p2f=p2f.numpy().astype(np.int16),
+               bary_checksum=bary.detach().double().sum(dim=(1, 2, 3)).numpy(), zbuf_checksum=zbuf.detach().double().sum(dim=(1, 2)).numpy())
+    out.update({"solve_" + k: v for k, v in _solve_fixture(sc, 2, 300, 0).items()})
+    np.savez_compressed(os.path.join(GOLD, "oracle_full.npz"), **out)
+    print("oracle_full.npz written")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["leaf", "small", "full"]
+    torch.set_num_threads(8)
+    if "leaf" in what:
+        gen_leaf()
+    if "small" in what:
+        gen_small()
+    if "full" in what:
+        gen_full()
