@@ -107,6 +107,16 @@ int nemo_render_backward(nemo_mesh_t mesh, const nemo_camera* cam, const float* 
 int nemo_clutter_score(const float* feat, const float* clutter, int32_t B, int32_t C, int32_t HW,
                        int32_t K, float* out, void* stream);
 
+/* ---- re-centring resample ---------------------------------------------------------------------
+ * align_no_centered (batch_solve_pose.py:65-90, with tensor_linspace nemo/utils/general.py:11-40):
+ * shifts / rescales feature maps (or clutter score maps, C = 1) so that an object seen with principal
+ * point p_src at distance dist_src looks as if centred at p_tgt at distance dist_tgt; bilinear
+ * grid_sample with align_corners = false; border = 1 is padding_mode='border', 0 is 'zeros'.
+ * src [n,C,h1,w1]; dist_src, dist_tgt [n]; p_src, p_tgt [n,2] (x, y); out [n,C,h0,w0]. */
+int nemo_align_maps(const float* src, const float* dist_src, const float* dist_tgt, const float* p_src,
+                    const float* p_tgt, int32_t n, int32_t C, int32_t h1, int32_t w1, int32_t h0, int32_t w0,
+                    int32_t border, float* out, void* stream);
+
 /* ---- pose-grid scoring ---------------------------------------------------------------------
  * get_init_pos_rendered_dim0 (batch_solve_pose.py:128-164) with loss_fg_bg (:31-34):
  *   obj[b,n,p] = sum_c P[n,c,p] * feat[b,c,p]
@@ -147,6 +157,8 @@ int nemo_vertex_similarity(nemo_mesh_t mesh, const float* table, const float* cl
  * belong to (a shard of a larger batch passes the larger batch's size).
  * dof = 3: C and theta are optimised (4 scalars), principal fixed (batch_solve_pose.py:312-315)
  * dof = 6: C, theta and principal are optimised (:308-311).
+ * score_boxes [n_hyp,4] i32 (row0,row1,col0,col1) or NULL: crop of the map on which the reported
+ *                     score is computed (object_loss_fg_bg, batch_solve_pose.py:36-41,354-357).
  * out_pose [n_hyp,8]: cx, cy, cz, theta, px, py (after the last update), score (= per-image
  *                     loss_fg_bg of the LAST forward, i.e. before the last update, as
  *                     batch_solve_pose.py:345-359 computes it), loss of the first forward.
@@ -154,8 +166,8 @@ int nemo_vertex_similarity(nemo_mesh_t mesh, const float* table, const float* cl
 int nemo_solve(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, const float* clu,
                const int32_t* hyp_to_image, const float* init_campos /*[n_hyp,3]*/,
                const float* init_theta /*[n_hyp]*/, const float* init_principal /*[n_hyp,2] or NULL*/,
-               int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof, const nemo_adam* opt,
-               float* out_pose, float* out_loss_hist, void* stream);
+               const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
+               const nemo_adam* opt, float* out_pose, float* out_loss_hist, void* stream);
 
 /* camera_position_to_spherical_angle (nemo/utils/mesh.py:50-56) on device:
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */

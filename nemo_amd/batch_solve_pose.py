@@ -68,25 +68,52 @@ def _adam_from_cfg(cfg):
     return dict(lr=opt.get("lr", 1e-3), betas=betas, eps=opt.get("eps", 1e-8), lr_gamma=sch.get("gamma", 1.0))
 
 
+def align_no_centered(maps_source, distance_source, principal_source, maps_target_shape, distance_target, principal_target,
+                      padding_mode="zeros"):
+    """Drop-in for reference batch_solve_pose.py:65-90 (one resample launch)."""
+    n = maps_source.shape[0]
+    dev = maps_source.device
+    def vec(t, k):
+        t = torch.as_tensor(t, dtype=torch.float32, device=dev)
+        return t.reshape(-1, k).expand(n, k) if t.numel() == k else t.reshape(n, k)
+    shape = (int(maps_target_shape[0]), int(maps_target_shape[1]))
+    return ops.align_maps(maps_source, vec(distance_source, 1), vec(principal_source, 2), shape, vec(distance_target, 1),
+                          vec(principal_target, 2), padding_mode)
+
+
+def get_init_pos(inter_module, samples_pos, samples_theta, predicted_maps, clutter_scores=None, reset_distance=None):
+    """Initialisation without pre-rendered maps (reference batch_solve_pose.py:168-191): the pose grid is
+    rendered on the fly - once for all images, or per image at its own distance when reset_distance is given."""
+    with torch.no_grad():
+        if reset_distance is None:
+            maps = inter_module(samples_pos, samples_theta)
+            return get_init_pos_rendered_dim0(maps, samples_pos, samples_theta, predicted_maps, clutter_scores)
+        unit = torch.nn.functional.normalize(samples_pos)
+        idx, mn = [], []
+        for i in range(predicted_maps.shape[0]):
+            maps = inter_module(unit * reset_distance[i].float(), samples_theta)
+            _, j, m = ops.grid_score(maps, predicted_maps[i:i + 1], None if clutter_scores is None else clutter_scores[i:i + 1])
+            idx.append(j)
+            mn.append(m)
+        idx = torch.cat(idx).long()
+        return samples_pos[idx], samples_theta[idx], torch.cat(mn)
+
+
 def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendered, theta_pre_rendered,
                feature_pre_rendered, device="cuda", principal=None, pre_render=True, dof=3, bbox=None, **kwargs):
-    """Same contract as the reference: list (one per image) of
+    """Same contract as the reference (batch_solve_pose.py:194-372): a list (one entry per image) of
     dict(final=[dict(azimuth, elevation, theta, distance, principal=[px,py], score)],
          pre_compute_time, pre_rendering_time, optimization_time).
-    Extra keyword `global_batch`: size of the batch the images are a shard of (defaults to b)."""
+    kwargs: distance_source, distance_target (re-centring), down_sample_rate (bbox), and the extra
+    `global_batch`: size of the batch the images are a shard of (defaults to b)."""
     b, c, hm_h, hm_w = feature_map.shape
-    if bbox is not None:
-        raise NotImplementedError("bbox-cropped final score is not implemented")
-    if principal is not None or dof == 6:
-        raise NotImplementedError("re-centring (principal != None) and dof == 6 are not implemented yet")
-    if dof not in (3, 4):
+    if dof not in (3, 4, 6):
         raise ValueError("dof must be 3, 4 or 6")
     if cfg.inference.get("inter_mode", "bilinear") != "bilinear" or cfg.inference.get("blur_radius", 0.0) != 0.0:
         raise NotImplementedError("only inter_mode='bilinear' with blur_radius 0 is supported")
-    if cfg.get("optimize_translation", False):
-        raise NotImplementedError("optimize_translation is not implemented yet")
     adam = _adam_from_cfg(cfg)
     epochs = int(cfg.inference.epochs)
+    dev = feature_map.device
     pred = {}
 
     # Step 1: clutter score
@@ -98,23 +125,64 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     pred["pre_compute_time"] = t1 - t0
 
     # Step 2: initialisation by pose-grid scoring
-    if pre_render:
-        init_C, init_theta, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
-                                                           theta_pre_rendered, feature_map, clutter_score)
+    cams = inter_module.rasterizer.cameras
+    size = cams.image_size                       # [1, 2] = (H, W)
+    target_shape = (int(size[0, 0]), int(size[0, 1]))
+    centre = size.flip(1) / 2                    # principal point of a centred image (x, y)
+    if dof in (3, 4):
+        if principal is not None:
+            principal = principal.float().to(dev)
+            t_feature_map = align_no_centered(feature_map, kwargs["distance_source"], principal, target_shape,
+                                              kwargs["distance_target"], centre)
+            t_clutter_score = align_no_centered(clutter_score[:, None], kwargs["distance_source"], principal, target_shape,
+                                                kwargs["distance_target"], centre).squeeze(1)
+            init_principal = principal
+            cams._N = b
+        else:
+            init_principal = None
+            t_feature_map, t_clutter_score = feature_map, clutter_score
+        if pre_render:
+            init_C, init_theta, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
+                                                               theta_pre_rendered, t_feature_map, t_clutter_score)
+        else:
+            ds = kwargs.get("distance_source")
+            init_C, init_theta, _ = get_init_pos(inter_module, cam_pos_pre_rendered, theta_pre_rendered, feature_map,
+                                                 clutter_score, reset_distance=None if ds is None else ds.float())
     else:
-        with torch.no_grad():
-            maps = inter_module(cam_pos_pre_rendered, theta_pre_rendered)
-        init_C, init_theta, _ = get_init_pos_rendered_dim0(maps, cam_pos_pre_rendered, theta_pre_rendered,
-                                                           feature_map, clutter_score)
+        assert pre_render
+        principal = principal.float().to(dev)
+        ones = torch.ones(b, device=dev)
+        all_C, all_theta, all_loss = [], [], []
+        for principal_ in principal:
+            t_feature_map = align_no_centered(feature_map, ones, principal_, target_shape, ones, centre, padding_mode="border")
+            t_clutter_score = align_no_centered(clutter_score[:, None], ones, principal_, target_shape, ones, centre,
+                                                padding_mode="border").squeeze(1)
+            this_C, this_theta, this_loss = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
+                                                                       theta_pre_rendered, t_feature_map, t_clutter_score)
+            all_C.append(this_C)
+            all_theta.append(this_theta)
+            all_loss.append(this_loss)
+        use = torch.min(torch.stack(all_loss), dim=0)[1]
+        ar = torch.arange(b, device=dev)
+        init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_theta)[use, ar]
+        init_principal = principal[use]
+        cams._N = b
     t2 = time.time()
     pred["pre_rendering_time"] = t2 - t1
 
     # Step 3: pose optimisation, all epochs on device
+    if principal is not None and dof == 3:
+        init_C = init_C / init_C.pow(2).sum(-1).pow(.5)[..., None] * kwargs["distance_source"].to(dev)[..., None].float()
+    opt_dof = 6 if (dof == 6 or cfg.get("optimize_translation", False)) else dof
     cam = inter_module.camera()
+    boxes = None
+    if bbox is not None:
+        rate = kwargs.get("down_sample_rate", 8)
+        boxes = torch.tensor([[int(float(v) / rate + .5) for v in bbox[i][:4]] for i in range(b)], dtype=torch.int32)
     table = ops.similarity_table(inter_module.mesh, feature_map)
-    pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, None, None,
-                        global_batch=kwargs.get("global_batch", b), dof=dof, steps=epochs,
-                        lr_every=epochs // 3 if epochs >= 3 else 0, **adam)
+    pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, init_principal, None,
+                        global_batch=kwargs.get("global_batch", b), dof=opt_dof, steps=epochs,
+                        lr_every=epochs // 3 if epochs >= 3 else 0, score_boxes=boxes, **adam)
     sph = ops.spherical_angles(pose[:, 0:3])
     host = torch.cat([pose, sph], dim=1).cpu().numpy()     # the one device->host copy
     t3 = time.time()

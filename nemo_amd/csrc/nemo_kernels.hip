@@ -392,6 +392,64 @@ extern "C" int nemo_clutter_score(const float* feat, const float* clutter, int32
 }
 
 // ------------------------------------------------------------------------------------------
+// re-centring resample (align_no_centered)
+// ------------------------------------------------------------------------------------------
+// out[n,c,y,x] = bilinear sample (align_corners = false) of src[n,c] at the grid
+//   gx(x) = (1 - t_x) * x_min[n] + t_x * x_max[n],  t_x = x / (w0 - 1)     (same for y)
+// with  x_min/max = 2 ps_x / w1 -/+ w0 / (w1 * rate) - 2 pt_x / w0,  rate = dist_source / dist_target.
+// border != 0: coordinates are clamped to the source (padding_mode='border'), else taps outside read 0.
+__global__ void align_kernel(const float* __restrict__ src, const float* __restrict__ dist_src,
+                             const float* __restrict__ dist_tgt, const float* __restrict__ p_src,
+                             const float* __restrict__ p_tgt, int C, int h1, int w1, int h0, int w0, int border,
+                             float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= h0 * w0) return;
+    const int y = q / w0, x = q - y * w0;
+    const float rate = dist_src[n] / dist_tgt[n];
+    const float psx = p_src[2 * n], psy = p_src[2 * n + 1], ptx = p_tgt[2 * n], pty = p_tgt[2 * n + 1];
+    const float fw0 = (float)w0, fh0 = (float)h0, fw1 = (float)w1, fh1 = (float)h1;
+    const float xmin = 2.0f * psx / fw1 - fw0 / (fw1 * rate) - ptx * 2.0f / fw0;
+    const float xmax = 2.0f * psx / fw1 + fw0 / (fw1 * rate) - ptx * 2.0f / fw0;
+    const float ymin = 2.0f * psy / fh1 - fh0 / (fh1 * rate) - pty * 2.0f / fh0;
+    const float ymax = 2.0f * psy / fh1 + fh0 / (fh1 * rate) - pty * 2.0f / fh0;
+    const float tx = w0 > 1 ? (float)x / (float)(w0 - 1) : 0.0f, ty = h0 > 1 ? (float)y / (float)(h0 - 1) : 0.0f;
+    const float gx = (1.0f - tx) * xmin + tx * xmax, gy = (1.0f - ty) * ymin + ty * ymax;
+    float ix = ((gx + 1.0f) * fw1 - 1.0f) / 2.0f, iy = ((gy + 1.0f) * fh1 - 1.0f) / 2.0f;
+    if (border) {
+        ix = fminf(fmaxf(ix, 0.0f), fw1 - 1.0f);
+        iy = fminf(fmaxf(iy, 0.0f), fh1 - 1.0f);
+    }
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx0, wx0 = 1.0f - wx1, wy1 = iy - fy0, wy0 = 1.0f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < w1, vx1 = x1 >= 0 && x1 < w1, vy0 = y0 >= 0 && y0 < h1, vy1 = y1 >= 0 && y1 < h1;
+    const int cx0 = min(max(x0, 0), w1 - 1), cx1 = min(max(x1, 0), w1 - 1), cy0 = min(max(y0, 0), h1 - 1), cy1 = min(max(y1, 0), h1 - 1);
+    const float w00 = (vx0 && vy0) ? wx0 * wy0 : 0.0f, w01 = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
+    const float w10 = (vx0 && vy1) ? wx0 * wy1 : 0.0f, w11 = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
+    const float* sp = src + (size_t)n * C * h1 * w1;
+    float* op = out + (size_t)n * C * h0 * w0 + q;
+    for (int c = 0; c < C; ++c) {
+        const float* sc = sp + (size_t)c * h1 * w1;
+        op[(size_t)c * h0 * w0] = sc[cy0 * w1 + cx0] * w00 + sc[cy0 * w1 + cx1] * w01 + sc[cy1 * w1 + cx0] * w10 + sc[cy1 * w1 + cx1] * w11;
+    }
+}
+
+extern "C" int nemo_align_maps(const float* src, const float* dist_src, const float* dist_tgt, const float* p_src,
+                               const float* p_tgt, int32_t n, int32_t C, int32_t h1, int32_t w1, int32_t h0, int32_t w0,
+                               int32_t border, float* out, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!src || !dist_src || !dist_tgt || !p_src || !p_tgt || !out || n < 0 || C <= 0 || h1 <= 0 || w1 <= 0 || h0 <= 0 || w0 <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_align_maps: bad argument");
+    if (n > 65535) return fail(NEMO_ERR_UNSUPPORTED, "nemo_align_maps: more than 65535 maps per call");
+    dim3 grid((h0 * w0 + 255) / 256, n);
+    hipLaunchKernelGGL(align_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dist_src, dist_tgt, p_src, p_tgt, C, h1,
+                       w1, h0, w0, border, out);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // dense pose-grid scoring
 // ------------------------------------------------------------------------------------------
 constexpr int GS_TN = 8, GS_TB = 8, GS_PIX = 256;
@@ -573,6 +631,7 @@ struct SolveArgs {
     RasterCtx rc;
     const float* table; const float* clu; const int32_t* hyp_to_image;
     const float* init_campos; const float* init_theta; const float* init_principal;
+    const int32_t* score_boxes;
     float def_px, def_py;
     int n_img; float inv_norm; int dof;
     int steps, lr_every;
@@ -611,6 +670,22 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         block_sum<2>(v2, s.red, s.tot);
         base_max = s.tot[0]; base_clu = s.tot[1];
     }
+    // optional crop for the reported score (rows [br0,br1) x cols [bc0,bc1) of the map)
+    int br0 = 0, br1 = H, bc0 = 0, bc1 = W;
+    float box_max = base_max, box_clu = base_clu, box_n = (float)HW;
+    if (a.score_boxes) {
+        br0 = max(a.score_boxes[4 * h], 0); br1 = min(a.score_boxes[4 * h + 1], H);
+        bc0 = max(a.score_boxes[4 * h + 2], 0); bc1 = min(a.score_boxes[4 * h + 3], W);
+        __syncthreads();
+        float v2[2] = {0.0f, 0.0f};
+        const int bw = max(bc1 - bc0, 0), bh = max(br1 - br0, 0);
+        for (int q = tid; q < bw * bh; q += blockDim.x) {
+            float cl = clu[(br0 + q / bw) * W + bc0 + q % bw];
+            v2[0] += fmaxf(0.0f, cl); v2[1] += cl;
+        }
+        block_sum<2>(v2, s.red, s.tot);
+        box_max = s.tot[0]; box_clu = s.tot[1]; box_n = (float)(bw * bh);
+    }
     const float fHW = (float)HW;
 #ifdef NEMO_STAMPS
     long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -631,13 +706,15 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         const int cnt = compact_covered(a.rc, s, &seg);
         STAMP(3);
 
-        float vals[15];
+        float vals[16];
+        const bool last = step == a.steps - 1;
         {
             PixelGrad acc;
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
             acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
             float dmax = 0.0f;      // sum over covered pixels of max(obj, clu) - max(0, clu)
+            float dbox = 0.0f;      // the same over the score crop (last step only)
             // The covered entries of this wave, four per lane at a time: all table / clutter loads of a
             // batch are issued before any of them is used, so one memory round trip covers the batch.
             constexpr int UNR = 2;
@@ -672,22 +749,24 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
                                 X2[3] = {s.vX[i2], s.vY[i2], fv.z2};
                     const float obj = pixel_score_and_grad(a.rc.cc, fv, X0, X1, X2, s.xs[px[u]], s.ys[py[u]], dd[u], cc_[u],
                                                            a.inv_norm, &acc);
-                    dmax += fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u]);
+                    const float dlt = fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u]);
+                    dmax += dlt;
+                    if (last && py[u] >= br0 && py[u] < br1 && px[u] >= bc0 && px[u] < bc1) dbox += dlt;
                 }
             }
 #pragma unroll
             for (int i = 0; i < 9; ++i) vals[i] = acc.M[i];
             vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2];
-            vals[12] = acc.gbx; vals[13] = acc.gby; vals[14] = dmax;
+            vals[12] = acc.gbx; vals[13] = acc.gby; vals[14] = dmax; vals[15] = dbox;
         }
         STAMP(4);
-        block_sum<15>(vals, s.red, s.tot);
+        block_sum<16>(vals, s.red, s.tot);
         STAMP(5);
 
         if (tid == 0) {
             float loss = 1.0f - ((base_max + s.tot[14]) / fHW - base_clu / fHW);
             if (step == 0) os->first_loss = loss;
-            os->last_loss = loss;
+            os->last_loss = a.score_boxes ? 1.0f - ((box_max + s.tot[15]) / box_n - box_clu / box_n) : loss;
             if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
             float g[6];
             pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
@@ -725,8 +804,9 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
 
 extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
                           const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
-                          const float* init_principal, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
-                          const nemo_adam* opt, float* out_pose, float* out_hist, void* stream) {
+                          const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
+                          int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
+                          void* stream) {
     if (n_hyp == 0) return NEMO_OK;
     if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
         return fail(NEMO_ERR_INVALID, "nemo_solve: bad argument");
@@ -741,6 +821,7 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     if (rcode) return rcode;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_principal;
+    a.score_boxes = score_boxes;
     a.def_px = cam->px; a.def_py = cam->py;
     a.n_img = n_img;
     a.inv_norm = 1.0f / ((float)global_batch * (float)(cam->H * cam->W));

@@ -27,7 +27,7 @@
 namespace nemo {
 
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kRasterThreads = 1024;
+constexpr int kRasterThreads = 512;
 constexpr int kRasterWaves = kRasterThreads / 64;
 constexpr int kMaxSide = 128;                // queue entry = xi | yi << 7 | face << 14
 constexpr int kPixBits = 14;
@@ -75,7 +75,7 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
     L.qcap = L.seg * kRasterWaves;
     if (L.qcap < 8192) L.qcap = 8192;
     L.queue = o; o = align16(o + 4 * L.qcap);
-    L.red = o; o = align16(o + 4 * 16 * kRasterWaves);
+    L.red = o; o = align16(o + 4 * 16 * 16);
     L.tot = o; o = align16(o + 4 * 16);
     L.pc = o; o = align16(o + (int)sizeof(PoseCam));
     L.opt = o; o = align16(o + 256);
@@ -151,10 +151,10 @@ __device__ inline void block_sum(const float* vals, float* red, float* tot) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         float sv = wave_sum(vals[k]);
-        if (lane == 0) red[k * kRasterWaves + wave] = sv;
+        if (lane == 0) red[k * 16 + wave] = sv;
     }
     __syncthreads();
-    if (threadIdx.x < NV * kRasterWaves) {      // one 16-lane row per value: lanes = the 16 waves' partials
+    if (threadIdx.x < NV * 16) {      // one 16-lane row per value: lanes = the waves' partials (zero padded)
         float sv = row16_sum(red[threadIdx.x]);
         if ((threadIdx.x & 15) == 0) tot[threadIdx.x >> 4] = sv;
     }
@@ -171,6 +171,7 @@ __device__ inline void raster_prologue(const RasterCtx& rc, const Lds& s) {
         for (int i = threadIdx.x; i < rc.F * 3; i += blockDim.x) s.faces[i] = rc.faces[i];
     for (int p = threadIdx.x; p < H * W; p += blockDim.x) s.zbuf[p] = kEmptyKey;
     if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s.red[i] = 0.0f;
 }
 
 template <bool FACES_LDS>
@@ -368,6 +369,7 @@ __device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigne
     const int HW = rc.cc.H * rc.cc.W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int* seg = s.queue + wave * rc.L.seg;
+    const float inv_w = 1.0f / (float)rc.cc.W;
     int count = 0;
     for (int c = wave; c * 64 < HW; c += kRasterWaves) {
         const int p = c * 64 + lane;
@@ -378,7 +380,7 @@ __device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigne
         const unsigned long long m = __ballot(cov);
         if (cov) {
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            const int yi = p / rc.cc.W;
+            const int yi = (int)(((float)p + 0.5f) * inv_w);       // exact for p < 2^22
             seg[count + rank] = pack_entry(p - yi * rc.cc.W, yi, (int)(key & 0xFFFFFFFFull));
         }
         count += __popcll(m);

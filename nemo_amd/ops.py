@@ -198,8 +198,27 @@ def vertex_similarity(mesh, table, clu, H, W, boxes=None):
     return out
 
 
+def align_maps(maps_source, distance_source, principal_source, target_shape, distance_target, principal_target,
+               padding_mode="zeros"):
+    """align_no_centered: maps_source [n,c,h1,w1] -> [n,c,h0,w0]; distances [n], principals [n,2] (x,y)."""
+    lib = _lib.load()
+    src = f32c(maps_source)
+    n, c, h1, w1 = src.shape
+    h0, w0 = int(target_shape[0]), int(target_shape[1])
+    if padding_mode not in ("zeros", "border"):
+        raise NotImplementedError("padding_mode must be 'zeros' or 'border'")
+    args = [f32c(t.to(src.device)).reshape(n, -1).contiguous() for t in (distance_source, distance_target, principal_source,
+                                                                         principal_target)]
+    out = torch.empty(n, c, h0, w0, device=src.device)
+    with torch.cuda.device(src.device):
+        check(lib.nemo_align_maps(ptr(src), ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), n, c, h1, w1, h0, w0,
+                                  1 if padding_mode == "border" else 0, ptr(out), stream_ptr()), "nemo_align_maps")
+    return out
+
+
 def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, hyp_to_image=None, global_batch=None,
-          dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, lr_gamma=0.2, lr_every=None, history=False):
+          dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, lr_gamma=0.2, lr_every=None, history=False,
+          score_boxes=None):
     """Runs the whole Adam loop on device.  -> (pose [n_hyp,8], loss_hist [n_hyp,steps] or None).
     pose columns: cx, cy, cz, theta, px, py, score (last forward), first-forward loss."""
     lib = _lib.load()
@@ -219,9 +238,13 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
     hist = torch.empty(n_hyp, steps, device=cp.device) if history else None
     cc = cam.c()
     gb = int(global_batch if global_batch is not None else n_img)
+    boxes = None
+    if score_boxes is not None:
+        boxes = score_boxes.to(device=cp.device, dtype=torch.int32).reshape(n_hyp, 4).contiguous()
     with torch.cuda.device(cp.device):
         check(lib.nemo_solve(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(cp), ptr(th), ptr(pr),
-                             n_hyp, n_img, gb, int(dof), C.byref(opt), ptr(out), ptr(hist), stream_ptr()), "nemo_solve")
+                             ptr(boxes, torch.int32), n_hyp, n_img, gb, int(dof), C.byref(opt), ptr(out), ptr(hist),
+                             stream_ptr()), "nemo_solve")
     return out, hist
 
 

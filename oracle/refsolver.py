@@ -469,7 +469,8 @@ def align_no_centered(maps_source, distance_source, principal_source, maps_targe
 
 
 def optimize_poses(inter, feature_map, clu, init_C, init_theta, init_principal=None, dof=3,
-                   epochs=300, lr=0.05, betas=(0.4, 0.6), gamma=0.2, global_batch=None, record=False):
+                   epochs=300, lr=0.05, betas=(0.4, 0.6), gamma=0.2, global_batch=None, record=False, bbox=None,
+                   down_sample_rate=8):
     """batch_solve_pose.py:306-338 - the Adam loop.  `global_batch` rescales the batch-mean loss so
     a shard of a larger batch reproduces the gradients it would see inside that batch."""
     b = feature_map.shape[0]
@@ -507,26 +508,74 @@ def optimize_poses(inter, feature_map, clu, init_C, init_theta, init_principal=N
         if (epo + 1) % (epochs // 3) == 0:
             sched.step()
     inter.principal = None
-    scores = torch.stack([loss_fg_bg(object_score[i, None].detach(), clu[i, None])[0] for i in range(b)])
+    if bbox is not None:
+        crop = lambda v: int(float(v) / down_sample_rate + .5)
+        scores = torch.stack([object_loss_fg_bg(object_score[i].detach(), clu[i], (crop(bbox[i][0]), crop(bbox[i][1])),
+                                                (crop(bbox[i][2]), crop(bbox[i][3])))[0] for i in range(b)])
+    else:
+        scores = torch.stack([loss_fg_bg(object_score[i, None].detach(), clu[i, None])[0] for i in range(b)])
     pr = principals.detach() if principals is not None else None
     return C.detach(), theta.detach(), pr, scores, hist
 
 
+def object_loss_fg_bg(obj_s, clu_s, object_height, object_width):
+    """batch_solve_pose.py:36-41."""
+    obj_s = obj_s[object_height[0]:object_height[1], object_width[0]:object_width[1]]
+    clu_s = clu_s[object_height[0]:object_height[1], object_width[0]:object_width[1]]
+    return torch.ones(1) - (torch.mean(torch.max(obj_s, clu_s)) - torch.mean(clu_s))
+
+
 def solve_pose(inter, feature_map, clutter_bank, cam_pos_pre_rendered, theta_pre_rendered,
                feature_pre_rendered, epochs=300, lr=0.05, betas=(0.4, 0.6), gamma=0.2,
-               global_batch=None, record=False):
-    """batch_solve_pose.py:194-372 for dof=3, principal=None, pre_render=True (the 3d_batch path)."""
+               global_batch=None, record=False, principal=None, dof=3, bbox=None, distance_source=None,
+               distance_target=None, down_sample_rate=8):
+    """batch_solve_pose.py:194-372 with pre_render=True: dof 3/4 (centred or re-centred) and dof 6."""
+    b = feature_map.shape[0]
     clu = clutter_score(feature_map, clutter_bank)
-    init_C, init_theta, init_loss, idx = get_init_pos_rendered_dim0(
-        feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered, feature_map, clu)
-    C, theta, _, scores, hist = optimize_poses(inter, feature_map, clu, init_C, init_theta, None, 3,
-                                               epochs, lr, betas, gamma, global_batch, record)
+    H, W = inter.cam.H, inter.cam.W
+    target = torch.tensor([[H, W]], dtype=torch.float32)
+    centre = target.flip(1) / 2
+    if dof in (3, 4):
+        if principal is not None:
+            t_fm = align_no_centered(feature_map, distance_source, principal, (H, W), distance_target,
+                                     centre.expand(b, -1))
+            t_clu = align_no_centered(clu[:, None], distance_source, principal, (H, W), distance_target,
+                                      centre.expand(b, -1)).squeeze(1)
+            init_principal = principal.float()
+        else:
+            t_fm, t_clu, init_principal = feature_map, clu, None
+        init_C, init_theta, init_loss, idx = get_init_pos_rendered_dim0(
+            feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered, t_fm, t_clu)
+    else:
+        ones = torch.ones(b)
+        all_C, all_t, all_l = [], [], []
+        for pr in principal:
+            pr_ = pr[None].expand(b, -1).float()
+            t_fm = align_no_centered(feature_map, ones, pr_, (H, W), ones, centre.expand(b, -1), padding_mode='border')
+            t_clu = align_no_centered(clu[:, None], ones, pr_, (H, W), ones, centre.expand(b, -1),
+                                      padding_mode='border').squeeze(1)
+            c_, t_, l_, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered,
+                                                        t_fm, t_clu)
+            all_C.append(c_); all_t.append(t_); all_l.append(l_)
+        use = torch.min(torch.stack(all_l), dim=0)[1]
+        ar = torch.arange(b)
+        init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_t)[use, ar]
+        init_principal = principal[use].float()
+        init_loss, idx = torch.stack(all_l)[use, ar], use
+    if principal is not None and dof == 3:
+        init_C = init_C / init_C.pow(2).sum(-1).pow(.5)[..., None] * distance_source[..., None].float()
+    C, theta, pr_out, scores, hist = optimize_poses(inter, feature_map, clu, init_C, init_theta, init_principal, dof,
+                                                    epochs, lr, betas, gamma, global_batch, record, bbox=bbox,
+                                                    down_sample_rate=down_sample_rate)
     dist, elev, azim = camera_position_to_spherical_angle(C)
     px, py = inter.cam.principal
-    preds = [dict(final=[dict(azimuth=azim[i].item(), elevation=elev[i].item(), theta=theta[i].item(),
-                              distance=dist[i].item(), principal=[px, py], score=scores[i].item())])
-             for i in range(feature_map.shape[0])]
-    return preds, dict(init_idx=idx, init_loss=init_loss, C=C, theta=theta, scores=scores, clutter=clu, hist=hist)
+    preds = []
+    for i in range(b):
+        pp = [px, py] if pr_out is None else [pr_out[i, 0].item(), pr_out[i, 1].item()]
+        preds.append(dict(final=[dict(azimuth=azim[i].item(), elevation=elev[i].item(), theta=theta[i].item(),
+                                      distance=dist[i].item(), principal=pp, score=scores[i].item())]))
+    return preds, dict(init_idx=idx, init_loss=init_loss, init_C=init_C, init_theta=init_theta, C=C, theta=theta,
+                       scores=scores, clutter=clu, hist=hist)
 
 
 # --------------------------------------------------------------------------------------

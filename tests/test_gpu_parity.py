@@ -322,3 +322,103 @@ def test_golden_solve(which, name, B, request):
     big = g.abs() > 1e-6
     assert torch.equal(torch.sign(moved)[big], -torch.sign(g)[big])
     assert torch.allclose(moved.abs()[big], torch.full_like(moved, 0.05)[big], atol=2e-3)
+
+
+# ---- re-centring, 6-D and cropped score ------------------------------------------------------------------
+def _offcentre_images(sc, B, principals, first_seed=60):
+    maps, gts = [], []
+    for i in range(B):
+        sc.ref.principal = principals[i:i + 1]
+        m, gt = R.synthetic_feature_map(sc.ref, sc.clutter, first_seed + i)
+        maps.append(m)
+        gts.append(gt)
+    sc.ref.principal = None
+    return torch.stack(maps), gts
+
+
+def test_align_maps(small):
+    from nemo_amd import ops
+    sc = small
+    fm, _ = sc.feature_maps(3, first_seed=7)
+    ds, dt = torch.tensor([5.0, 6.5, 4.0]), torch.full((3,), 5.0)
+    ps = torch.tensor([[20.0, 18.0], [30.5, 22.0], [25.0, 20.0]])
+    pt = torch.tensor([[sc.W / 2, sc.H / 2]]).expand(3, -1)
+    for mode in ("zeros", "border"):
+        ref = R.align_no_centered(fm, ds, ps, (sc.H, sc.W), dt, pt, padding_mode=mode)
+        got = ops.align_maps(fm.to(sc.device), ds.to(sc.device), ps.to(sc.device), (sc.H, sc.W), dt.to(sc.device),
+                             pt.to(sc.device), mode)
+        assert float((got.cpu() - ref).abs().max()) < 2e-5, mode
+
+
+def test_solve_pose_recentred_3d_and_bbox(small):
+    import nemo_amd
+    from nemo_amd.utils import default_pose3d_config
+    sc = small
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps_ref, cs_ref, th_ref = R.get_pre_render_samples(sc.ref, az, el, th, di)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    B = 3
+    principal = torch.tensor([[22.0, 18.0], [28.0, 23.0], [25.0, 20.0]])
+    fm, gts = _offcentre_images(sc, B, principal)
+    dsrc, dtgt = torch.full((B,), 5.0), torch.full((B,), 5.0)
+    bbox = torch.tensor([[40.0, 280.0, 60.0, 340.0]] * B)       # image pixels; rows then cols
+    ref_preds, aux = R.solve_pose(sc.ref, fm, sc.clutter, cs_ref, th_ref, maps_ref, principal=principal, dof=3, bbox=bbox,
+                                  distance_source=dsrc, distance_target=dtgt)
+    cfg = default_pose3d_config()
+    preds = nemo_amd.solve_pose(cfg, fm.to(sc.device), sc.mod, sc.clutter.to(sc.device), cs, ths, maps, device=sc.device,
+                                principal=principal.to(sc.device), dof=3, bbox=bbox, distance_source=dsrc.to(sc.device),
+                                distance_target=dtgt.to(sc.device), down_sample_rate=8)
+    for i in range(B):
+        got, ref = preds[i]["final"][0], ref_preds[i]["final"][0]
+        for k in ("azimuth", "elevation", "theta"):
+            assert angle_diff_deg(got[k], ref[k]) < 0.5, (i, k, got, ref)
+        assert abs(got["score"] - ref["score"]) < 2e-3
+        assert got["principal"] == [float(principal[i, 0]), float(principal[i, 1])]
+        assert R.pose_error(gts[i], got) * 180 / math.pi < 5.0
+
+
+def test_solve_pose_6d(small):
+    import nemo_amd
+    from nemo_amd.utils import default_pose3d_config
+    sc = small
+    az, el, th, _, _, _ = R.get_param_samples(GRID_CFG)
+    di = np.array([4.0, 6.0])
+    maps_ref, cs_ref, th_ref = R.get_pre_render_samples(sc.ref, az, el, th, di)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    assert torch.equal(cs.cpu(), cs_ref)
+    fr = torch.tensor([0.3, 0.5, 0.7])
+    cand = torch.stack((fr.view(-1, 1).expand(-1, 3) * sc.W, fr.view(1, -1).expand(3, -1) * sc.H)).view(2, -1).T.contiguous()
+    B = 3
+    gt_pr = torch.tensor([[16.0, 13.0], [34.0, 27.0], [26.0, 21.0]])
+    fm, gts = _offcentre_images(sc, B, gt_pr, first_seed=80)
+    ref_preds, aux = R.solve_pose(sc.ref, fm, sc.clutter, cs_ref, th_ref, maps_ref, principal=cand, dof=6)
+    cfg = default_pose3d_config()
+    preds = nemo_amd.solve_pose(cfg, fm.to(sc.device), sc.mod, sc.clutter.to(sc.device), cs, ths, maps, device=sc.device,
+                                principal=cand.to(sc.device), dof=6)
+    for i in range(B):
+        got, ref = preds[i]["final"][0], ref_preds[i]["final"][0]
+        for k in ("azimuth", "elevation", "theta"):
+            assert angle_diff_deg(got[k], ref[k]) < 0.5, (i, k, got, ref)
+        assert abs(got["distance"] - ref["distance"]) < 0.05
+        assert abs(got["principal"][0] - ref["principal"][0]) < 0.2 and abs(got["principal"][1] - ref["principal"][1]) < 0.2
+        assert abs(got["score"] - ref["score"]) < 2e-3
+        assert abs(got["principal"][0] - float(gt_pr[i, 0])) < 1.5 and abs(got["principal"][1] - float(gt_pr[i, 1])) < 1.5
+
+
+def test_dof6_first_steps_track_oracle(small):
+    """The principal-point gradient path: six steps with dof = 6 against the oracle's autograd + Adam."""
+    from nemo_amd import ops
+    sc = small
+    fm, gts = sc.feature_maps(3, first_seed=20)
+    clu = R.clutter_score(fm, sc.clutter)
+    C0, th0 = random_poses(3, seed=4, dist=(4.8, 5.2))
+    pr0 = torch.tensor([[24.0, 19.0], [26.5, 21.0], [25.0, 20.0]])
+    Cr, thr, prr, scores, hist = R.optimize_poses(sc.ref, fm, clu, C0, th0, pr0, 6, epochs=6, record=True)
+    tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
+    pose, lh = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu.to(sc.device), C0.to(sc.device), th0.to(sc.device),
+                         pr0.to(sc.device), dof=6, steps=6, history=True)
+    pose = pose.cpu()
+    per_image = torch.stack([h["per_image"] for h in hist], dim=1)
+    assert rel_err(lh, per_image) < REL
+    assert rel_err(pose[:, 0:3], Cr) < 1e-4 and float((pose[:, 3] - thr).abs().max()) < 1e-4
+    assert float((pose[:, 4:6] - prr).abs().max()) < 1e-3

@@ -219,8 +219,8 @@ def test_solve_pose_rejects_unsupported_modes():
     from nemo_amd.utils import default_pose3d_config
     cfg = default_pose3d_config()
     fm = torch.rand(1, 8, 4, 5)
-    with pytest.raises(NotImplementedError):
-        nemo_amd.solve_pose(cfg, fm, None, torch.rand(1, 8), None, None, None, bbox=torch.zeros(1, 4))
+    with pytest.raises(ValueError):
+        nemo_amd.solve_pose(cfg, fm, None, torch.rand(1, 8), None, None, None, dof=5)
     cfg.inference.optimizer["class_name"] = "torch.optim.SGD"
     with pytest.raises(NotImplementedError):
         nemo_amd.solve_pose(cfg, fm, None, torch.rand(1, 8), None, None, None)
