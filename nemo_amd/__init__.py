@@ -6,7 +6,9 @@ this package is the host-side mirror of the reference interface for that path.
 from . import ops
 from .batch_solve_pose import get_pre_render_samples, solve_pose
 from .cameras import MeshRasterizer, PerspectiveCameras, RasterizationSettings
+from .feature_banks import FeatureBankNeMo
 from .mesh_interpolate_module import MeshInterpolateModule
+from .nemo import NeMo, classify_by_render_compare
 
 __all__ = ["ops", "get_pre_render_samples", "solve_pose", "MeshRasterizer", "PerspectiveCameras",
-           "RasterizationSettings", "MeshInterpolateModule"]
+           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "NeMo", "classify_by_render_compare"]

@@ -422,3 +422,39 @@ def test_dof6_first_steps_track_oracle(small):
     assert rel_err(lh, per_image) < REL
     assert rel_err(pose[:, 0:3], Cr) < 1e-4 and float((pose[:, 3] - thr).abs().max()) < 1e-4
     assert float((pose[:, 4:6] - prr).abs().max()) < 1e-3
+
+
+# ---- model façade -----------------------------------------------------------------------------------------
+def test_nemo_facade_evaluate_and_fast_inference(small):
+    import nemo_amd
+    from nemo_amd.utils import default_pose3d_config
+    sc = small
+    cfg = default_pose3d_config()
+    clutter_rows = torch.nn.functional.normalize(torch.randn(64, sc.C, generator=torch.Generator().manual_seed(3)), dim=1)
+    ckpt = dict(memory=torch.cat([sc.mem, clutter_rows]))
+    model = nemo_amd.NeMo(cfg, "car", mode="test", checkpoint=ckpt, mesh=(sc.verts, sc.faces), image_size=(sc.H * 8, sc.W * 8),
+                          device=str(sc.device), inference=nemo_amd.utils.ConfigNode({"cameras": {"focal_length": 375.0 / 2 * 8}}))
+    B = 3
+    maps, gts = [], []
+    for i in range(B):
+        m, gt = R.synthetic_feature_map(sc.ref, model.clutter_bank.cpu(), 300 + i)
+        maps.append(m)
+        gts.append(gt)
+    sample = dict(img=torch.stack(maps), azimuth=torch.tensor([g["azimuth"] for g in gts]),
+                  elevation=torch.tensor([g["elevation"] for g in gts]), theta=torch.tensor([g["theta"] for g in gts]),
+                  distance=torch.full((B,), 5.0), this_name=[f"im{i}" for i in range(B)],
+                  bbox=torch.tensor([[0.0, sc.H * 8, 0.0, sc.W * 8]] * B))
+    preds, cls = model.evaluate(sample)
+    assert len(preds) == B and set(cls) == {"im0", "im1", "im2"}
+    for p in preds:
+        assert p["pose_error"] * 180 / math.pi < 5.0
+    sims = model.fast_inference(sample)
+    fm = sample["img"]
+    for i in range(B):
+        m = fm[i].reshape(sc.C, -1)
+        ref = torch.maximum((sc.mem @ m).max(dim=0)[0], (model.clutter_bank.cpu() @ m).view(-1)).mean()
+        assert abs(float(sims[i]) - float(ref)) < 1e-5
+    bank = nemo_amd.FeatureBankNeMo(input_size=sc.C, num_pos=sc.verts.shape[0], num_noise=0)
+    assert bank.memory.shape == (sc.verts.shape[0], sc.C)
+    labels, scores = nemo_amd.classify_by_render_compare({"car": model}, sample)
+    assert labels == ["car"] * B and scores.shape == (B, 1)
