@@ -304,6 +304,7 @@ __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderB
     PixelGrad acc;
     for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
     acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
+    const ViewInv vinv = view_inv(a.rc.cc, s);
     for (int i = threadIdx.x & 63; i < cnt; i += 64) {
         int xi, yi, f, i0, i1, i2;
         unpack_entry(seg[i], &xi, &yi, &f);
@@ -317,8 +318,8 @@ __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderB
             const float* mt = a.memory_t + (size_t)c * V;
             gb[0] += g * mt[i0]; gb[1] += g * mt[i1]; gb[2] += g * mt[i2];
         }
-        float X0[3] = {s.vX[i0], s.vY[i0], s.vZ[i0]}, X1[3] = {s.vX[i1], s.vY[i1], s.vZ[i1]},
-              X2[3] = {s.vX[i2], s.vY[i2], s.vZ[i2]};
+        float X0[3], X1[3], X2[3];
+        view_coords(vinv, fv, X0, X1, X2);
         pixel_backward(a.rc.cc, fv, X0, X1, X2, s.xs[xi], s.ys[yi], gb, &acc);
     }
     float vals[14];
@@ -452,7 +453,7 @@ extern "C" int nemo_align_maps(const float* src, const float* dist_src, const fl
 // ------------------------------------------------------------------------------------------
 // dense pose-grid scoring
 // ------------------------------------------------------------------------------------------
-constexpr int GS_TN = 8, GS_TB = 8, GS_PIX = 256;
+constexpr int GS_TN = 12, GS_TB = 16, GS_PIX = 256;
 
 // partial[ptile][b][n] = sum over the tile's pixels of max(obj, clu) (or obj when clu == nullptr)
 __global__ __launch_bounds__(GS_PIX) void grid_score_kernel(const float* __restrict__ pre, const float* __restrict__ feat,
@@ -625,6 +626,7 @@ struct OptState {
     float P[6], m[6], v[6];
     double lr, b1p, b2p;
     float first_loss, last_loss;
+    float base_max, base_clu, box_max, box_clu, box_n;   // per-image constants of the loss (see solve_kernel)
 };
 
 struct SolveArgs {
@@ -663,16 +665,20 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         os->first_loss = 0.0f; os->last_loss = 0.0f;
     }
     // per-image constants of the loss: sum_p max(0, clu) (what an uncovered image scores) and sum_p clu
-    float base_max, base_clu;
+    // They are parked in the optimiser state (dedicated LDS words written once by thread 0): s.tot is
+    // reused by every later reduction.
     {
         float v2[2] = {0.0f, 0.0f};
         for (int p = tid; p < HW; p += blockDim.x) { float cl = clu[p]; v2[0] += fmaxf(0.0f, cl); v2[1] += cl; }
         block_sum<2>(v2, s.red, s.tot);
-        base_max = s.tot[0]; base_clu = s.tot[1];
+        if (tid == 0) {
+            os->base_max = s.tot[0]; os->base_clu = s.tot[1];
+            os->box_max = s.tot[0]; os->box_clu = s.tot[1]; os->box_n = (float)HW;
+        }
+        __syncthreads();
     }
     // optional crop for the reported score (rows [br0,br1) x cols [bc0,bc1) of the map)
     int br0 = 0, br1 = H, bc0 = 0, bc1 = W;
-    float box_max = base_max, box_clu = base_clu, box_n = (float)HW;
     if (a.score_boxes) {
         br0 = max(a.score_boxes[4 * h], 0); br1 = min(a.score_boxes[4 * h + 1], H);
         bc0 = max(a.score_boxes[4 * h + 2], 0); bc1 = min(a.score_boxes[4 * h + 3], W);
@@ -684,7 +690,8 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
             v2[0] += fmaxf(0.0f, cl); v2[1] += cl;
         }
         block_sum<2>(v2, s.red, s.tot);
-        box_max = s.tot[0]; box_clu = s.tot[1]; box_n = (float)(bw * bh);
+        if (tid == 0) { os->box_max = s.tot[0]; os->box_clu = s.tot[1]; os->box_n = (float)(bw * bh); }
+        __syncthreads();
     }
     const float fHW = (float)HW;
 #ifdef NEMO_STAMPS
@@ -699,6 +706,9 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         project_vertices(a.rc, s);
         STAMP(1);
         raster_pass1<FL>(a.rc, s);
+#ifdef NEMO_STAMPS_P1
+        if (tid == 0 && a.out_hist) for (int k = 0; k < 3; ++k) a.out_hist[(size_t)h * a.steps + 8 + k] += s.tot[k] / (float)a.steps;
+#endif
         STAMP(7);
         raster_pass2<FL>(a.rc, s);
         STAMP(2);
@@ -715,6 +725,7 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
             acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
             float dmax = 0.0f;      // sum over covered pixels of max(obj, clu) - max(0, clu)
             float dbox = 0.0f;      // the same over the score crop (last step only)
+            const ViewInv vinv = view_inv(a.rc.cc, s);
             // The covered entries of this wave, four per lane at a time: all table / clutter loads of a
             // batch are issued before any of them is used, so one memory round trip covers the batch.
             constexpr int UNR = 2;
@@ -745,8 +756,8 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
                     if (!ok[u]) continue;
                     const int i0 = vi[u][0], i1 = vi[u][1], i2 = vi[u][2];
                     FaceVerts fv = face_verts(s, i0, i1, i2);
-                    const float X0[3] = {s.vX[i0], s.vY[i0], fv.z0}, X1[3] = {s.vX[i1], s.vY[i1], fv.z1},
-                                X2[3] = {s.vX[i2], s.vY[i2], fv.z2};
+                    float X0[3], X1[3], X2[3];
+                    view_coords(vinv, fv, X0, X1, X2);
                     const float obj = pixel_score_and_grad(a.rc.cc, fv, X0, X1, X2, s.xs[px[u]], s.ys[py[u]], dd[u], cc_[u],
                                                            a.inv_norm, &acc);
                     const float dlt = fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u]);
@@ -764,9 +775,9 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         STAMP(5);
 
         if (tid == 0) {
-            float loss = 1.0f - ((base_max + s.tot[14]) / fHW - base_clu / fHW);
+            float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
             if (step == 0) os->first_loss = loss;
-            os->last_loss = a.score_boxes ? 1.0f - ((box_max + s.tot[15]) / box_n - box_clu / box_n) : loss;
+            os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
             if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
             float g[6];
             pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
@@ -796,6 +807,7 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         float* o = a.out_pose + (size_t)h * 8;
         for (int k = 0; k < 6; ++k) o[k] = os->P[k];
         o[6] = os->last_loss; o[7] = os->first_loss;
+
 #ifdef NEMO_STAMPS
         if (a.out_hist) for (int k = 0; k < 8; ++k) a.out_hist[(size_t)h * a.steps + k] = (float)stamp_acc[k] / (float)a.steps;
 #endif

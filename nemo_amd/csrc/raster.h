@@ -2,7 +2,7 @@
 // One workgroup (16 waves) owns one camera pose; everything lives in LDS.  The kernels are bound by
 // vector-instruction issue, so the structure is about executing as few wave-instructions as possible:
 //
-//   project_vertices   every vertex -> view coordinates + NDC xy (5 floats, struct of arrays)
+//   project_vertices   every vertex -> NDC xy + view depth (one float4 record per vertex)
 //   raster_pass1       one face per lane, registers only.  A conservative bounding box, then a cheap
 //                      conservative edge-sign test (fma arithmetic with an error margin) over its pixels;
 //                      survivors are recorded in a 64-bit mask.  The wave reserves queue space with one
@@ -42,8 +42,8 @@ __device__ inline void unpack_entry(unsigned int e, int* xi, int* yi, int* f) {
 
 struct LdsLayout {
     int zbuf;                   // u64 [HW]
-    int vX, vY, vZ, vxn, vyn;   // f32 [V] each
-    int faces;                  // i32 [F*3] (or -1: faces are read from global memory)
+    int verts;                  // float4 [V]: NDC x, NDC y, view depth, unused
+    int faces;                  // int4 [F]: three vertex indices (or -1: faces are read from global memory)
     int xs, ys;                 // f32 [W], [H]: NDC centre of pixel column xi / row yi
     int queue;                  // u32 [qcap]: pair queue, later the per-wave covered segments
     int qcap;                   // entries
@@ -62,12 +62,8 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
     const int HW = H * W;
     int o = 0;
     L.zbuf = o; o = align16(o + 8 * HW);
-    L.vX = o; o = align16(o + 4 * V);
-    L.vY = o; o = align16(o + 4 * V);
-    L.vZ = o; o = align16(o + 4 * V);
-    L.vxn = o; o = align16(o + 4 * V);
-    L.vyn = o; o = align16(o + 4 * V);
-    if (faces_in_lds) { L.faces = o; o = align16(o + 12 * F); } else L.faces = -1;
+    L.verts = o; o = align16(o + 16 * V);
+    if (faces_in_lds) { L.faces = o; o = align16(o + 16 * F); } else L.faces = -1;
     L.xs = o; o = align16(o + 4 * W);
     L.ys = o; o = align16(o + 4 * H);
     const int chunks = (HW + 63) / 64;
@@ -93,8 +89,8 @@ struct RasterCtx {
 
 struct Lds {
     unsigned long long* zbuf;
-    float *vX, *vY, *vZ, *vxn, *vyn;
-    int32_t* faces;     // LDS copy or nullptr
+    float4* verts;
+    int4* faces;        // LDS copy or nullptr
     float *xs, *ys, *red, *tot;
     unsigned int* queue;
     unsigned int* qcount;    // [2]: pairs in the near half, pairs in the far half
@@ -105,9 +101,8 @@ struct Lds {
 __device__ inline Lds carve(char* base, const LdsLayout& L) {
     Lds s;
     s.zbuf = (unsigned long long*)(base + L.zbuf);
-    s.vX = (float*)(base + L.vX); s.vY = (float*)(base + L.vY); s.vZ = (float*)(base + L.vZ);
-    s.vxn = (float*)(base + L.vxn); s.vyn = (float*)(base + L.vyn);
-    s.faces = L.faces >= 0 ? (int32_t*)(base + L.faces) : nullptr;
+    s.verts = (float4*)(base + L.verts);
+    s.faces = L.faces >= 0 ? (int4*)(base + L.faces) : nullptr;
     s.xs = (float*)(base + L.xs); s.ys = (float*)(base + L.ys);
     s.red = (float*)(base + L.red); s.tot = (float*)(base + L.tot);
     s.queue = (unsigned int*)(base + L.queue);
@@ -162,30 +157,46 @@ __device__ inline void block_sum(const float* vals, float* red, float* tot) {
 }
 
 // ---- front end ------------------------------------------------------------------------------------
-// One-time per-workgroup set-up: pixel-centre tables, the face list, an empty key buffer.
+// One-time per-workgroup set-up: pixel-centre tables, the face list, an empty key buffer.  Ends with a barrier.
 __device__ inline void raster_prologue(const RasterCtx& rc, const Lds& s) {
     const int H = rc.cc.H, W = rc.cc.W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) s.xs[i] = pix_to_ndc(W - 1 - i, W, H);
     for (int i = threadIdx.x; i < H; i += blockDim.x) s.ys[i] = pix_to_ndc(H - 1 - i, H, W);
     if (s.faces)
-        for (int i = threadIdx.x; i < rc.F * 3; i += blockDim.x) s.faces[i] = rc.faces[i];
+        for (int i = threadIdx.x; i < rc.F; i += blockDim.x)
+            s.faces[i] = make_int4(rc.faces[3 * i], rc.faces[3 * i + 1], rc.faces[3 * i + 2], 0);
     for (int p = threadIdx.x; p < H * W; p += blockDim.x) s.zbuf[p] = kEmptyKey;
     if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s.red[i] = 0.0f;
+    __syncthreads();      // the reduction scratch must be zero before any wave writes a partial into it
 }
 
 template <bool FACES_LDS>
 __device__ inline void load_face(const RasterCtx& rc, const Lds& s, int f, int* i0, int* i1, int* i2) {
-    if (FACES_LDS) { *i0 = s.faces[3 * f + 0]; *i1 = s.faces[3 * f + 1]; *i2 = s.faces[3 * f + 2]; }
+    if (FACES_LDS) { const int4 t = s.faces[f]; *i0 = t.x; *i1 = t.y; *i2 = t.z; }
     else { *i0 = rc.faces[3 * f + 0]; *i1 = rc.faces[3 * f + 1]; *i2 = rc.faces[3 * f + 2]; }
 }
 
 __device__ inline FaceVerts face_verts(const Lds& s, int i0, int i1, int i2) {
     FaceVerts fv;
-    fv.x0 = s.vxn[i0]; fv.y0 = s.vyn[i0]; fv.z0 = s.vZ[i0];
-    fv.x1 = s.vxn[i1]; fv.y1 = s.vyn[i1]; fv.z1 = s.vZ[i1];
-    fv.x2 = s.vxn[i2]; fv.y2 = s.vyn[i2]; fv.z2 = s.vZ[i2];
+    const float4 a = s.verts[i0], b = s.verts[i1], c = s.verts[i2];
+    fv.x0 = a.x; fv.y0 = a.y; fv.z0 = a.z;
+    fv.x1 = b.x; fv.y1 = b.y; fv.z1 = b.z;
+    fv.x2 = c.x; fv.y2 = c.y; fv.z2 = c.z;
     return fv;
+}
+
+// View-space X, Y of the face's vertices recovered from their NDC position and depth
+// (x_ndc = a X / Z + bx); used by the backward chain only.
+struct ViewInv { float ia, bx, by; };
+__device__ inline ViewInv view_inv(const CamConst& cc, const Lds& s) {
+    ViewInv v; v.ia = 1.0f / cc.a; v.bx = s.pc->bx; v.by = s.pc->by; return v;
+}
+__device__ inline void view_coords(const ViewInv& vi, const FaceVerts& fv, float* X0, float* X1, float* X2) {
+    const float ia = vi.ia, bx = vi.bx, by = vi.by;
+    X0[0] = (fv.x0 - bx) * fv.z0 * ia; X0[1] = (fv.y0 - by) * fv.z0 * ia; X0[2] = fv.z0;
+    X1[0] = (fv.x1 - bx) * fv.z1 * ia; X1[1] = (fv.y1 - by) * fv.z1 * ia; X1[2] = fv.z1;
+    X2[0] = (fv.x2 - bx) * fv.z2 * ia; X2[1] = (fv.y2 - by) * fv.z2 * ia; X2[2] = fv.z2;
 }
 
 // Pose camera in s.pc must be visible (barrier before).  Ends with a barrier.
@@ -199,8 +210,7 @@ __device__ inline void project_vertices(const RasterCtx& rc, const Lds& s) {
     for (int v = threadIdx.x; v < rc.V; v += blockDim.x) {
         float Xv[3], xn, yn;
         project_vertex(rc.cc, R, T, bx, by, rc.verts[3 * v], rc.verts[3 * v + 1], rc.verts[3 * v + 2], Xv, &xn, &yn);
-        s.vX[v] = Xv[0]; s.vY[v] = Xv[1]; s.vZ[v] = Xv[2];
-        s.vxn[v] = xn; s.vyn[v] = yn;
+        s.verts[v] = make_float4(xn, yn, Xv[2], 0.0f);
     }
     __syncthreads();
 }
@@ -244,6 +254,12 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
     const float x_org = -0.5f * rx + 0.5f * dx, y_org = -0.5f * ry + 0.5f * dy;
     const float inv_dx = (float)W / rx, inv_dy = (float)H / ry;
     const float z_mid3 = 3.0f * s.pc->T[2];          // three times the view depth of the object origin
+#ifdef NEMO_STAMPS_P1
+    long long tq0 = clock64(), tq[4] = {0, 0, 0, 0};
+#define P1STAMP(i) do { long long t_ = clock64(); tq[i] += t_ - tq0; tq0 = t_; } while (0)
+#else
+#define P1STAMP(i) do { } while (0)
+#endif
     for (int base = 0; base < rc.F; base += blockDim.x) {
         const int f = base + threadIdx.x;
         FaceVerts fv = {};
@@ -279,20 +295,39 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
             tol = 2e-5f * ext * mag;      // >> the rounding error of either evaluation (a few 1e-7 * ext * mag)
             if (!(tol == tol) || !zpos) tol = __builtin_inff();   // odd geometry: keep every pixel of the box
         }
-        unsigned long long mask = 0;
+        P1STAMP(0);
+        // Candidate pixels, one row of the box at a time: inside means e_i(x, y) >= -tol for the three
+        // oriented edge planes, i.e. a_i * t + s_i >= 0 in box-column units t, which is an interval of t.
+        // mask bit (r * 8 + c) = column c of row r may be inside.
+        unsigned int mask_lo = 0, mask_hi = 0;        // rows 0-3, rows 4-7
         int cnt_near = 0, cnt_far = 0;
         if (ok) {
             if (nx <= 8 && ny <= 8) {
+                const float x0 = __builtin_fmaf((float)jx0, dx, x_org);
+                const float a0 = A0 * dx, a1 = A1 * dx, a2 = A2 * dx;
+                const float i0 = -__builtin_amdgcn_rcpf(a0), i1 = -__builtin_amdgcn_rcpf(a1), i2 = -__builtin_amdgcn_rcpf(a2);
+                const float k0 = __builtin_fmaf(A0, x0, C0) + tol, k1 = __builtin_fmaf(A1, x0, C1) + tol,
+                            k2 = __builtin_fmaf(A2, x0, C2) + tol;
+                const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+                const float tiny = 1e-20f;
                 for (int r = 0; r < ny; ++r) {
                     const float yf = __builtin_fmaf((float)(jy0 + r), dy, y_org);
-                    const float r0 = __builtin_fmaf(B0, yf, C0), r1 = __builtin_fmaf(B1, yf, C1), r2 = __builtin_fmaf(B2, yf, C2);
-                    for (int c = 0; c < nx; ++c) {
-                        const float xf = __builtin_fmaf((float)(jx0 + c), dx, x_org);
-                        const float e0 = __builtin_fmaf(A0, xf, r0), e1 = __builtin_fmaf(A1, xf, r1), e2 = __builtin_fmaf(A2, xf, r2);
-                        if (!(fminf(fminf(e0, e1), e2) < -tol)) mask |= 1ull << (r * 8 + c);
+                    const float s0 = __builtin_fmaf(B0, yf, k0), s1 = __builtin_fmaf(B1, yf, k1), s2 = __builtin_fmaf(B2, yf, k2);
+                    const float q0 = s0 * i0, q1 = s1 * i1, q2 = s2 * i2;      // root of a_i * t + s_i
+                    float lo = fmaxf(fmaxf(a0 > tiny ? q0 : ninf, a1 > tiny ? q1 : ninf), a2 > tiny ? q2 : ninf);
+                    float hi = fminf(fminf(a0 < -tiny ? q0 : pinf, a1 < -tiny ? q1 : pinf), a2 < -tiny ? q2 : pinf);
+                    // an edge parallel to the row decides the whole row
+                    const bool dead = (fabsf(a0) <= tiny && s0 < 0.0f) || (fabsf(a1) <= tiny && s1 < 0.0f) ||
+                                      (fabsf(a2) <= tiny && s2 < 0.0f);
+                    lo = fmaxf(ceilf(lo - 1e-3f), 0.0f);
+                    hi = fminf(floorf(hi + 1e-3f), (float)(nx - 1));
+                    if (!dead && lo <= hi) {
+                        const int cl = (int)lo, ch = (int)hi;
+                        const unsigned int bits = ((2u << ch) - 1u) & ~((1u << cl) - 1u);
+                        if (r < 4) mask_lo |= bits << (r * 8); else mask_hi |= bits << ((r - 4) * 8);
                     }
                 }
-                const int n = __popcll(mask);
+                const int n = __popc(mask_lo) + __popc(mask_hi);
                 cnt_near = near ? n : 0;
                 cnt_far = near ? 0 : n;
             } else {
@@ -301,6 +336,7 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
                     for (int jx = jx0; jx < jx0 + nx; ++jx) eval_pair(f, fv, W - 1 - jx, H - 1 - jy, W, s);
             }
         }
+        P1STAMP(1);
         int total;
         const int incl = wave_inclusive_scan(cnt_near | (cnt_far << 16), &total);
         if (total) {
@@ -314,16 +350,25 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
             const int excl = incl - (cnt_near | (cnt_far << 16));
             unsigned int slot = near ? bn + (unsigned)(excl & 0xFFFF) : bf + (unsigned)(excl >> 16);
             const int off = near ? 0 : half;
-            while (mask) {
-                const int k = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int xi = W - 1 - (jx0 + (k & 7)), yi = H - 1 - (jy0 + (k >> 3));
-                if (slot < (unsigned)half) s.queue[off + slot] = pack_entry(xi, yi, f);
-                else eval_pair(f, fv, xi, yi, W, s);          // queue half full: evaluate in place
-                ++slot;
+#pragma unroll
+            for (int halfsel = 0; halfsel < 2; ++halfsel) {
+                unsigned int m = halfsel ? mask_hi : mask_lo;
+                while (m) {
+                    const int k = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int xi = W - 1 - (jx0 + (k & 7)), yi = H - 1 - (jy0 + (k >> 3) + 4 * halfsel);
+                    if (slot < (unsigned)half) s.queue[off + slot] = pack_entry(xi, yi, f);
+                    else eval_pair(f, fv, xi, yi, W, s);          // queue half full: evaluate in place
+                    ++slot;
+                }
             }
         }
+        P1STAMP(2);
     }
+#ifdef NEMO_STAMPS_P1
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 512) { float* d = (float*)(s.red); (void)d; }
+    if (threadIdx.x == 64) { s.tot[0] = (float)tq[0]; s.tot[1] = (float)tq[1]; s.tot[2] = (float)tq[2]; }
+#endif
     __syncthreads();
 }
 

@@ -47,26 +47,45 @@ __global__ __launch_bounds__(256) void table_gemm_kernel(const float* __restrict
     const int va0c = va0_ok ? va0 : 0, va1c = va1_ok ? va1 : 0, pb0c = pb0_ok ? pb0 : 0, pb1c = pb1_ok ? pb1 : 0;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    // K loop in chunks of 8 channels (4 MFMA k-steps), register double-buffered: the loads of chunk
+    // i+1 are in flight while the 16 MFMAs of chunk i issue.
+    const float* qa0 = memT + va0c;
+    const float* qa1 = memT + va1c;
+    const float* qb0 = fb + pb0c;
+    const float* qb1 = fb + pb1c;
+    float a0[4], a1[4], b0[4], b1[4], na0[4], na1[4], nb0[4], nb1[4];
+    const int nfull = C / 8;
+    auto load_chunk = [&](int k, float* x0, float* x1, float* y0, float* y1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t kk = (size_t)(k + 2 * u + lk);
+            x0[u] = qa0[kk * V]; x1[u] = qa1[kk * V];
+            y0[u] = qb0[kk * HW]; y1[u] = qb1[kk * HW];
+        }
+    };
+    auto mfma_chunk = [&](const float* x0, const float* x1, const float* y0, const float* y1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float p0 = va0_ok ? x0[u] : 0.0f, p1 = va1_ok ? x1[u] : 0.0f;
+            const float q0 = pb0_ok ? y0[u] : 0.0f, q1 = pb1_ok ? y1[u] : 0.0f;
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, q0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, q1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, q0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, q1, acc11, 0, 0, 0);
+        }
+    };
     int k = 0;
-    for (; k + 8 <= C; k += 8) {
-        float a0[4], a1[4], b0[4], b1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = k + 2 * u + lk;
-            a0[u] = memT[(size_t)kk * V + va0c];
-            a1[u] = memT[(size_t)kk * V + va1c];
-            b0[u] = fb[(size_t)kk * HW + pb0c];
-            b1[u] = fb[(size_t)kk * HW + pb1c];
+    if (nfull > 0) {
+        load_chunk(0, a0, a1, b0, b1);
+        int i = 0;
+        for (; i + 2 <= nfull; i += 2) {
+            load_chunk((i + 1) * 8, na0, na1, nb0, nb1);
+            mfma_chunk(a0, a1, b0, b1);
+            if (i + 2 < nfull) load_chunk((i + 2) * 8, a0, a1, b0, b1);
+            mfma_chunk(na0, na1, nb0, nb1);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float x0 = va0_ok ? a0[u] : 0.0f, x1 = va1_ok ? a1[u] : 0.0f;
-            const float y0 = pb0_ok ? b0[u] : 0.0f, y1 = pb1_ok ? b1[u] : 0.0f;
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc11, 0, 0, 0);
-        }
+        if (i < nfull) mfma_chunk(a0, a1, b0, b1);
+        k = nfull * 8;
     }
     for (; k < C; k += 2) {
         const int kk = k + lk;

