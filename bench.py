@@ -129,7 +129,7 @@ def main():
     fm, gts = synthetic_images(mod, clutter, B, first_seed=rank * B, dev=dev)
     cam = mod.camera()
     S = max(1, args.streams)
-    tables = [torch.empty(B, mod.mesh.V, H * W, device=dev) for _ in range(S)]
+    tables = [torch.empty(ops.table_shape(mod.mesh, B, H * W), device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     gathered = [torch.empty(B, 7, device=dev) for _ in range(world)] if world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]

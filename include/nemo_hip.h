@@ -135,7 +135,14 @@ int nemo_grid_score(const float* pre, const float* feat, const float* clu, int32
  * (nemo/models/solve_pose.py:120-124) and the matmul of NeMo.fast_inference
  * (nemo/models/nemo.py:350), computed once per image on the matrix cores so that the
  * optimisation loop touches three scalars per covered pixel instead of 4 x C floats.
- * feat [B,C,HW] -> table [B,V,HW] (f32). */
+ * feat [B,C,HW] -> table (f32) laid out [B][PT = ceil(HW/128)][VG = ceil(V/4)][128][4]: element
+ *   (b,v,p) at (((b * PT + p / 128) * VG + v / 4) * 128 + p % 128) * 4 + v % 4;
+ * pixels past HW and vertices past V (padding) are written as zeros.
+ * nemo_similarity_table_elems returns the number of floats per image.  The matrix-core result
+ * registers map onto whole 16-byte elements of this layout, each pixel tile is one contiguous
+ * block, and the optimisation loop finds the values of neighbouring vertices for neighbouring
+ * pixels in the same cache lines. */
+size_t nemo_similarity_table_elems(nemo_mesh_t mesh, int32_t HW);
 int nemo_similarity_table(nemo_mesh_t mesh, const float* feat, int32_t B, int32_t HW, float* table,
                           void* stream);
 
@@ -151,7 +158,7 @@ int nemo_vertex_similarity(nemo_mesh_t mesh, const float* table, const float* cl
  *   render at (C,theta[,principal]) -> obj = <interpolated features, feat> per pixel ->
  *   loss_fg_bg with clutter -> backward to the pose parameters -> Adam -> LR schedule.
  * n_hyp hypotheses; hypothesis h refines against image hyp_to_image[h] (NULL: image h).
- * table [n_img,V,HW] from nemo_similarity_table, clu [n_img,HW].
+ * table [n_img] images in the layout of nemo_similarity_table, clu [n_img,HW].
  * The loss of the reference is a mean over the whole batch (global_batch images x HW pixels),
  * which sets the gradient scale seen by Adam's eps: pass the size of the batch the images
  * belong to (a shard of a larger batch passes the larger batch's size).

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libnemo_hip.so")
 SYMBOLS = [
     "nemo_last_error", "nemo_version", "nemo_mesh_create", "nemo_mesh_set_memory", "nemo_mesh_destroy",
     "nemo_mesh_info", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
-    "nemo_grid_score_workspace", "nemo_grid_score", "nemo_similarity_table", "nemo_vertex_similarity",
+    "nemo_grid_score_workspace", "nemo_grid_score", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
     "nemo_solve", "nemo_spherical_angles",
 ]
 
@@ -57,6 +57,8 @@ def load():
     lib.nemo_grid_score_workspace.argtypes = [i32, i32, i32]
     lib.nemo_grid_score_workspace.restype = C.c_size_t
     lib.nemo_grid_score.argtypes = [f32p, f32p, f32p, i32, i32, i32, i32, f32p, vp, f32p, vp, C.c_size_t, vp]
+    lib.nemo_similarity_table_elems.argtypes = [vp, i32]
+    lib.nemo_similarity_table_elems.restype = C.c_size_t
     lib.nemo_similarity_table.argtypes = [vp, f32p, i32, i32, f32p, vp]
     lib.nemo_vertex_similarity.argtypes = [vp, f32p, f32p, vp, i32, i32, i32, f32p, vp]
     lib.nemo_solve.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, f32p, f32p, f32p, vp, i32, i32, i32, i32,

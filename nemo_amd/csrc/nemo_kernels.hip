@@ -58,8 +58,29 @@ struct nemo_mesh_s {
     int32_t* faces;    // [F,3]
     float* memory;     // [V,C]
     float* memory_t;   // [C,V]
+    void* bank_frag;   // vertex bank as bf16-piece MFMA fragments (table_gemm.hip), or null when C does not qualify
     int device;
 };
+
+// Layout of the similarity table: [image][pixel tile = ceil(HW / 128)][vertex group = ceil(V / 4)][128][4]:
+// element (v, p) of an image at ((p / 128 * VG + v / 4) * 128 + p % 128) * 4 + v % 4.  The producer's
+// accumulator registers map onto whole 16-byte elements and each pixel tile is one contiguous block;
+// the values of a vertex and of its neighbours in the vertex order, for neighbouring pixels, share
+// cache lines.
+constexpr int kTabTile = 128, kTabShift = 7;
+__host__ __device__ inline size_t table_image_elems(int V, int HW) {
+    return (size_t)((HW + kTabTile - 1) >> kTabShift) * ((V + 3) >> 2) * kTabTile * 4;
+}
+__device__ inline int table_offset(int vg_n, int v, int p) {          // within one image; fits 32 bits for maps <= 128 x 128
+    return ((((p >> kTabShift) * vg_n + (v >> 2)) << kTabShift) + (p & (kTabTile - 1))) * 4 + (v & 3);
+}
+
+namespace nemo {
+bool split_table_supported(int C);
+size_t split_bank_bytes(int V, int C);
+void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_t st);
+int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
+}
 
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -80,7 +101,7 @@ extern "C" int nemo_mesh_create(const float* verts, const int32_t* faces, int32_
     if (!verts || !faces || !out || V <= 0 || F <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_create: bad argument");
     nemo_mesh_s* m = new (std::nothrow) nemo_mesh_s();
     if (!m) return fail(NEMO_ERR_INVALID, "out of host memory");
-    m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr;
+    m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr; m->bank_frag = nullptr;
     HIP_TRY(hipGetDevice(&m->device));
     HIP_TRY(hipMalloc((void**)&m->verts, sizeof(float) * 3 * V));
     HIP_TRY(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * F));
@@ -98,11 +119,14 @@ extern "C" int nemo_mesh_set_memory(nemo_mesh_t m, const float* memory, int32_t 
         if (m->memory_t) { HIP_TRY(hipFree(m->memory_t)); m->memory_t = nullptr; }
         HIP_TRY(hipMalloc((void**)&m->memory, sizeof(float) * (size_t)m->V * C));
         HIP_TRY(hipMalloc((void**)&m->memory_t, sizeof(float) * (size_t)m->V * C));
+        if (m->bank_frag) { HIP_TRY(hipFree(m->bank_frag)); m->bank_frag = nullptr; }
+        if (nemo::split_table_supported(C)) HIP_TRY(hipMalloc(&m->bank_frag, nemo::split_bank_bytes(m->V, C)));
         m->C = C;
     }
     HIP_TRY(hipMemcpyAsync(m->memory, memory, sizeof(float) * (size_t)m->V * C, hipMemcpyDeviceToDevice, st));
     dim3 grid((C + 31) / 32, (m->V + 31) / 32), block(32, 8);
     hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, m->memory, m->memory_t, m->V, C);
+    if (m->bank_frag) nemo::launch_split_bank(m->memory, m->bank_frag, m->V, C, st);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }
@@ -113,6 +137,7 @@ extern "C" int nemo_mesh_destroy(nemo_mesh_t m) {
     if (m->faces) (void)hipFree(m->faces);
     if (m->memory) (void)hipFree(m->memory);
     if (m->memory_t) (void)hipFree(m->memory_t);
+    if (m->bank_frag) (void)hipFree(m->bank_frag);
     delete m;
     return NEMO_OK;
 }
@@ -593,9 +618,9 @@ __global__ void vertex_similarity_kernel(const float* __restrict__ table, const 
     float s = 0.0f;
     for (int q = threadIdx.x; q < np; q += blockDim.x) {
         int p = (r0 + q / bw) * W + c0 + q % bw;
-        const float* t = table + (size_t)b * V * HW + p;
+        const float* t = table + (size_t)b * table_image_elems(V, HW);
         float best = -__builtin_inff();
-        for (int v = 0; v < V; ++v) best = fmaxf(best, t[(size_t)v * HW]);
+        for (int v = 0; v < V; ++v) best = fmaxf(best, t[table_offset((V + 3) >> 2, v, p)]);
         s += fmaxf(best, clu[(size_t)b * HW + p]);
     }
     s = wave_sum(s);
@@ -648,7 +673,8 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
     const int h = blockIdx.x, tid = threadIdx.x;
     const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
     const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
-    const float* tab = a.table + (size_t)img * V * HW;
+    const float* tab = a.table + (size_t)img * table_image_elems(V, HW);
+    const int vg_n = (V + 3) >> 2;
     const float* clu = a.clu + (size_t)img * HW;
     raster_prologue(a.rc, s);
 
@@ -745,9 +771,9 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
                 for (int u = 0; u < UNR; ++u) {
                     const int p = py[u] * W + px[u];
                     if (ok[u]) {
-                        dd[u][0] = tab[(size_t)vi[u][0] * HW + p];
-                        dd[u][1] = tab[(size_t)vi[u][1] * HW + p];
-                        dd[u][2] = tab[(size_t)vi[u][2] * HW + p];
+                        dd[u][0] = tab[table_offset(vg_n, vi[u][0], p)];
+                        dd[u][1] = tab[table_offset(vg_n, vi[u][1], p)];
+                        dd[u][2] = tab[table_offset(vg_n, vi[u][2], p)];
                         cc_[u] = clu[p];
                     } else { dd[u][0] = dd[u][1] = dd[u][2] = 0.0f; cc_[u] = 0.0f; }
                 }
@@ -882,11 +908,18 @@ namespace nemo {
 int launch_table_gemm(const float* memT, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
 }
 
+extern "C" size_t nemo_similarity_table_elems(nemo_mesh_t m, int32_t HW) {
+    if (!m || HW <= 0) return 0;
+    return table_image_elems(m->V, HW);
+}
+
 extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B, int32_t HW, float* table, void* stream) {
     if (B == 0) return NEMO_OK;
     if (!m || !feat || !table || B < 0 || HW <= 0) return fail(NEMO_ERR_INVALID, "nemo_similarity_table: bad argument");
     if (!m->memory_t) return fail(NEMO_ERR_STATE, "nemo_similarity_table: mesh has no vertex memory");
-    if (nemo::launch_table_gemm(m->memory_t, feat, table, m->V, m->C, HW, B, (hipStream_t)stream))
+    const int rc = m->bank_frag ? nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, (hipStream_t)stream)
+                                : nemo::launch_table_gemm(m->memory_t, feat, table, m->V, m->C, HW, B, (hipStream_t)stream);
+    if (rc)
         return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table: too many tiles for one launch");
     HIP_TRY(hipGetLastError());
     return NEMO_OK;

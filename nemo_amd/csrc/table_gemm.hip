@@ -1,18 +1,30 @@
-// Vertex x pixel similarity table on the gfx950 f32 matrix cores.
+// Vertex x pixel similarity table on the gfx950 matrix cores.
 //
 //   table[b, v, p] = sum_c memory[v, c] * feat[b, c, p]
 //
 // the reference's kpt_score_map (nemo/models/solve_pose.py:120-124) and the matmul of
-// NeMo.fast_inference (nemo/models/nemo.py:350).  Both operands are read "k-major":
-// A = memory^T [C, V] (the transpose is kept by the mesh handle) and B = feat[b] [C, HW], so the
-// lanes of every fragment load touch consecutive addresses and no LDS staging is needed.
-// v_mfma_f32_32x32x2_f32 accumulates an exact f32 fma chain over c (k order 0,1,2,...), i.e. the
-// same numerics as a scalar float loop.
+// NeMo.fast_inference (nemo/models/nemo.py:350).
 //
-// Tiling: one wave owns a 64 x 64 output tile (2 x 2 MFMA tiles, 64 accumulator registers); a
-// workgroup is 4 waves in a 2 x 2 arrangement = 128 vertices x 128 pixels.  Workgroups that share
-// a pixel tile of one image are consecutive in the per-XCD order so its feature columns stay in
-// that XCD's L2.
+// Two kernels:
+//
+//  * split_table_kernel (the one used when C is a multiple of 16 and <= 128): every f32 operand is
+//    written as a sum of three bf16 pieces x = h + m + l (each piece the round-to-nearest bf16 of what
+//    the previous ones left over, so the three carry 24 mantissa bits), and the product is
+//    accumulated in f32 by v_mfma_f32_32x32x16_bf16 over the six piece pairs whose weight is
+//    >= 2^-16 relative: hh, hm, mh, hl, lh, mm.  The dropped pairs are below f32 resolution; the
+//    result is as close to the exact dot product as an f32 fma chain is (measured: smaller rms
+//    error than an f32 matmul), at 6/16 of the f32 matrix-core cost (the bf16 pipe has 16 x
+//    the rate of the f32 pipe), so the six products are 2.7 x faster and the kernel becomes bound by writing
+//    the table to HBM.  The vertex bank is split once per nemo_mesh_set_memory into MFMA fragment
+//    order; the feature tile of a workgroup (128 pixels x C channels) is split once into LDS and
+//    reused for every vertex block.
+//
+//  * table_gemm_kernel (any C): v_mfma_f32_32x32x2_f32, an exact f32 fma chain over c.  Both
+//    operands are read "k-major": A = memory^T [C, V] (the transpose is kept by the mesh handle)
+//    and B = feat[b] [C, HW], so the lanes of every fragment load touch consecutive addresses and
+//    no LDS staging is needed.  One wave owns a 64 x 64 output tile (2 x 2 MFMA tiles); a workgroup
+//    is 4 waves = 128 vertices x 128 pixels; workgroups that share a pixel tile of one image are
+//    consecutive in the per-XCD order so its feature columns stay in that XCD's L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -101,19 +113,23 @@ __global__ __launch_bounds__(256) void table_gemm_kernel(const float* __restrict
         acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc11, 0, 0, 0);
     }
 
-    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* tb = table + (size_t)b * V * HW;
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
+    // registers 4j..4j+3 of a lane are four consecutive vertices of one pixel, one 16-byte element of
+    // the table ([b][pixel tile][vertex group of 4][128 pixels][4]); columns past HW hold zeros and
+    // the vertices that pad the last group are written as zeros.
+    const int vg_n = (V + 3) >> 2;
+    float4* tb = reinterpret_cast<float4*>(table) + ((size_t)b * npt + pt) * vg_n * TG_BN;
+    const int ca = wc * 64 + lr, cb = ca + 32;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
-        const int r0 = v0 + row, r1 = v0 + 32 + row;
-        if (r0 < V) {
-            if (pb0_ok) tb[(size_t)r0 * HW + pb0] = acc00[reg];
-            if (pb1_ok) tb[(size_t)r0 * HW + pb1] = acc01[reg];
+    for (int j = 0; j < 4; ++j) {
+        const int g0 = (v0 + 8 * j + 4 * lk) >> 2, g1 = g0 + 8;
+        if (g0 < vg_n) {
+            tb[(size_t)g0 * TG_BN + ca] = make_float4(acc00[4 * j], acc00[4 * j + 1], acc00[4 * j + 2], acc00[4 * j + 3]);
+            tb[(size_t)g0 * TG_BN + cb] = make_float4(acc01[4 * j], acc01[4 * j + 1], acc01[4 * j + 2], acc01[4 * j + 3]);
         }
-        if (r1 < V) {
-            if (pb0_ok) tb[(size_t)r1 * HW + pb0] = acc10[reg];
-            if (pb1_ok) tb[(size_t)r1 * HW + pb1] = acc11[reg];
+        if (g1 < vg_n) {
+            tb[(size_t)g1 * TG_BN + ca] = make_float4(acc10[4 * j], acc10[4 * j + 1], acc10[4 * j + 2], acc10[4 * j + 3]);
+            tb[(size_t)g1 * TG_BN + cb] = make_float4(acc11[4 * j], acc11[4 * j + 1], acc11[4 * j + 2], acc11[4 * j + 3]);
         }
     }
 }
@@ -124,6 +140,285 @@ int launch_table_gemm(const float* memT, const float* feat, float* table, int V,
     if (nwg > 0x7FFFFFFFLL) return -1;
     hipLaunchKernelGGL(table_gemm_kernel, dim3((unsigned)nwg), dim3(256), 0, st, memT, feat, table, V, C, HW, nvt, npt,
                        (int)nwg);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// split-bf16 path
+// ---------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));     // 8 bf16 bit patterns (one MFMA operand fragment)
+
+constexpr int SG_NP = 3;            // bf16 pieces per f32 value
+constexpr int SG_PT = 128;          // pixels per workgroup
+constexpr int SG_THREADS = 512;     // 8 waves: 4 (vertex blocks of 64) x 2 (pixel blocks of 64)
+
+// Round-to-nearest-even bf16 pair of two finite floats, packed lo | hi << 16.
+__device__ inline uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// Split 8 floats into SG_NP x 8 bf16 pieces: out[piece] holds the 8 values' piece as 4 packed dwords.
+__device__ inline void split8(const float x[8], uint4 out[SG_NP]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = x[j];
+#pragma unroll
+    for (int pc = 0; pc < SG_NP; ++pc) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[j] = pack_bf16(r[2 * j], r[2 * j + 1]);
+            if (pc + 1 < SG_NP) {          // remainders are exact in f32
+                r[2 * j] -= __uint_as_float(w[j] << 16);
+                r[2 * j + 1] -= __uint_as_float(w[j] & 0xFFFF0000u);
+            }
+        }
+        out[pc] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Vertex bank -> MFMA A-operand fragments: frag[((piece * nvb + vb) * nks + ks) * 64 + lane] holds
+// rows vb*32 + (lane & 31), channels ks*16 + 8*(lane >> 5) .. +7; rows >= V are zero.
+__global__ void split_bank_kernel(const float* __restrict__ memory, uint4* __restrict__ frag, int V, int C, int nvb) {
+    const int nks = C / 16;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvb * nks * 64) return;
+    const int lane = i & 63, ks = (i >> 6) % nks, vb = (i >> 6) / nks;
+    const int row = vb * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = row < V ? memory[(size_t)row * C + k0 + j] : 0.0f;
+    uint4 pcs[SG_NP];
+    split8(x, pcs);
+#pragma unroll
+    for (int pc = 0; pc < SG_NP; ++pc) frag[((size_t)(pc * nvb + vb) * nks + ks) * 64 + lane] = pcs[pc];
+}
+
+__device__ inline bf16x8 as_frag(const uint4& u) {
+    union { uint4 u; bf16x8 f; } c; c.u = u; return c.f;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Stores register quads [J0, J1) of the four accumulator tiles of one wave into its pixel tile of the
+// table (tile: [vertex group][128 pixels] 16-byte elements; col = the lane's first pixel column, the
+// second is col + 32).  A quad is four consecutive vertices of one pixel = one element, so a store
+// instruction writes two contiguous 512-byte runs.  CHECK = false: the caller guarantees that all 64
+// rows exist, and the stores are straight-line code.
+template <int J0, int J1, bool CHECK>
+__device__ inline void store_quads(f32x4* __restrict__ tile, const f32x16& c00, const f32x16& c01, const f32x16& c10,
+                                   const f32x16& c11, int v0, int vg_n, int lk, int col) {
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        const int g0 = (v0 >> 2) + 2 * j + lk, g1 = g0 + 8;
+        if (!CHECK || g0 < vg_n) {
+            __builtin_nontemporal_store((f32x4){c00[4 * j], c00[4 * j + 1], c00[4 * j + 2], c00[4 * j + 3]}, tile + g0 * SG_PT + col);
+            __builtin_nontemporal_store((f32x4){c01[4 * j], c01[4 * j + 1], c01[4 * j + 2], c01[4 * j + 3]}, tile + g0 * SG_PT + col + 32);
+        }
+        if (!CHECK || g1 < vg_n) {
+            __builtin_nontemporal_store((f32x4){c10[4 * j], c10[4 * j + 1], c10[4 * j + 2], c10[4 * j + 3]}, tile + g1 * SG_PT + col);
+            __builtin_nontemporal_store((f32x4){c11[4 * j], c11[4 * j + 1], c11[4 * j + 2], c11[4 * j + 3]}, tile + g1 * SG_PT + col + 32);
+        }
+    }
+}
+
+template <int NKS>
+struct SplitWave {
+    const uint4* bank_frag; const char* bbase; f32x4* tile;
+    size_t apiece; int vg_n, lane, lk, col;
+    static constexpr int C = NKS * 16;
+    static constexpr int row_bytes = C * 2 + 16;      // +16: consecutive pixels start 4 banks apart
+    static constexpr int piece_bytes = SG_PT * row_bytes;
+    static constexpr int QPK = (4 + NKS - 1) / NKS;   // result register quads stored per k-step
+
+    template <int KS>
+    __device__ inline void store_slice(const f32x16& o00, const f32x16& o01, const f32x16& o10, const f32x16& o11, int v0) const {
+        constexpr int J0 = KS * QPK < 4 ? KS * QPK : 4, J1 = (KS + 1) * QPK < 4 ? (KS + 1) * QPK : 4;
+        store_quads<J0, J1, false>(tile, o00, o01, o10, o11, v0, vg_n, lk, col);
+    }
+
+    // One 64 x 64 result tile (vertex blocks vb0, vb0 + 1).  The A fragments of k-step ks+1 are requested
+    // before the MFMAs of k-step ks.  STORE_PREV: the 16 stores of the previous tile (o.., all of it
+    // inside the table) are spread over the k-steps, each slice issued after the A request, so that
+    // waiting for the fragments never waits for a store (gfx9 counts loads and stores in one in-order
+    // counter).
+    template <bool STORE_PREV>
+    __device__ inline void tile_mma(int vb0, f32x16& acc00, f32x16& acc01, f32x16& acc10, f32x16& acc11, const f32x16& o00,
+                                const f32x16& o01, const f32x16& o10, const f32x16& o11, int prev_v0) const {
+        const uint4* a0p = bank_frag + ((size_t)vb0 * NKS) * 64 + lane;
+        const uint4* a1p = a0p + (size_t)NKS * 64;
+        uint4 na0[SG_NP], na1[SG_NP];
+#pragma unroll
+#ifdef TG_NOALOAD
+        for (int pc = 0; pc < SG_NP; ++pc) { na0[pc] = make_uint4(lane, pc, vb0, 3); na1[pc] = make_uint4(lane, pc + 5, vb0, 7); }
+#else
+        for (int pc = 0; pc < SG_NP; ++pc) { na0[pc] = a0p[pc * apiece]; na1[pc] = a1p[pc * apiece]; }
+#endif
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 a0[SG_NP], a1[SG_NP], b0[SG_NP], b1[SG_NP];
+#pragma unroll
+            for (int pc = 0; pc < SG_NP; ++pc) { a0[pc] = as_frag(na0[pc]); a1[pc] = as_frag(na1[pc]); }
+#ifndef TG_NOALOAD
+            if (ks + 1 < NKS) {
+#pragma unroll
+                for (int pc = 0; pc < SG_NP; ++pc) {
+                    na0[pc] = a0p[pc * apiece + (size_t)(ks + 1) * 64];
+                    na1[pc] = a1p[pc * apiece + (size_t)(ks + 1) * 64];
+                }
+            }
+#endif
+#pragma unroll
+            for (int pc = 0; pc < SG_NP; ++pc) {
+                b0[pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + ks * 32));
+                b1[pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + 32 * row_bytes + ks * 32));
+            }
+#ifdef TG_NOSTORE
+            if (STORE_PREV && o00[0] == 12345.678f) {
+#else
+            if (STORE_PREV) {
+#endif
+                switch (ks) {          // ks is a compile-time constant after unrolling
+                    case 0: store_slice<0>(o00, o01, o10, o11, prev_v0); break;
+                    case 1: store_slice<1>(o00, o01, o10, o11, prev_v0); break;
+                    case 2: store_slice<2>(o00, o01, o10, o11, prev_v0); break;
+                    case 3: store_slice<3>(o00, o01, o10, o11, prev_v0); break;
+                    case 4: store_slice<4>(o00, o01, o10, o11, prev_v0); break;
+                    case 5: store_slice<5>(o00, o01, o10, o11, prev_v0); break;
+                    case 6: store_slice<6>(o00, o01, o10, o11, prev_v0); break;
+                    default: store_slice<7>(o00, o01, o10, o11, prev_v0); break;
+                }
+            }
+            // piece pairs in increasing weight: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int ia = q == 0 ? 2 : q == 1 ? 0 : q == 2 ? 1 : q == 3 ? 1 : 0;
+                const int ib = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : q == 3 ? 0 : q == 4 ? 1 : 0;
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ia], b0[ib], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ia], b1[ib], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ia], b0[ib], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ia], b1[ib], acc11, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);        // keep the k-steps apart: registers for one step's operands only
+        }
+    }
+};
+
+// NKS = C / 16 k-steps, fully unrolled.
+template <int NKS>
+__global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const uint4* __restrict__ bank_frag,
+                                                                 const float* __restrict__ feat, float* __restrict__ table,
+                                                                 int V, int nvb, int HW, int npt) {
+    extern __shared__ __align__(16) char sg_lds[];
+    using W = SplitWave<NKS>;
+    constexpr int C = W::C, row_bytes = W::row_bytes, piece_bytes = W::piece_bytes;
+    const int pt = blockIdx.x % npt, b = blockIdx.x / npt;
+    const int p0 = pt * SG_PT;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* fb = feat + (size_t)b * C * HW;
+
+    // ---- phase 1: feature tile -> bf16 pieces in LDS, [piece][pixel][channel] ----
+    {
+        const int pl = t & (SG_PT - 1);
+        const int p = p0 + pl;
+        const bool pok = p < HW;
+        const float* col = fb + (pok ? p : HW - 1);
+        constexpr int KG_STEP = SG_THREADS / SG_PT, NKG = C / 8;
+        constexpr int NIT = (NKG + KG_STEP - 1) / KG_STEP;
+        float x[NIT][8];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int kg = t / SG_PT + it * KG_STEP;
+            const int kgc = kg < NKG ? kg : NKG - 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[it][j] = col[(size_t)(kgc * 8 + j) * HW];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int kg = t / SG_PT + it * KG_STEP;
+            if (kg < NKG) {
+                if (!pok) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[it][j] = 0.0f;
+                }
+                uint4 pcs[SG_NP];
+                split8(x[it], pcs);
+#pragma unroll
+                for (int pc = 0; pc < SG_NP; ++pc)
+                    *reinterpret_cast<uint4*>(sg_lds + pc * piece_bytes + pl * row_bytes + kg * 16) = pcs[pc];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: all vertex blocks against the resident pixel tile ----
+    const int wr = wave >> 1, wc = wave & 1;
+    W w;
+    w.bank_frag = bank_frag; w.lane = lane; w.lk = lane >> 5;
+    w.bbase = sg_lds + (wc * 64 + (lane & 31)) * row_bytes + w.lk * 16;
+    w.vg_n = (V + 3) >> 2;
+    w.tile = reinterpret_cast<f32x4*>(table) + ((size_t)b * npt + pt) * w.vg_n * SG_PT;
+    w.apiece = (size_t)nvb * NKS * 64;
+    w.col = wc * 64 + (lane & 31);
+
+    int vb0 = wr * 2;                                  // nvb is even: blocks vb0 and vb0 + 1 both exist
+    if (vb0 >= nvb) return;
+    // Only the last tile of a wave can hang over the end of the vertex list, and the last tile is stored
+    // by the checked epilogue: every tile stored inside the pipelined loop is complete.  Pixel columns
+    // past HW exist in the table (zero features give zeros).
+    f32x16 o00 = {0}, o01 = {0}, o10 = {0}, o11 = {0};
+    {
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        w.template tile_mma<false>(vb0, acc00, acc01, acc10, acc11, o00, o01, o10, o11, 0);
+        o00 = acc00; o01 = acc01; o10 = acc10; o11 = acc11;
+    }
+    int prev_v0 = vb0 * 32;
+    for (vb0 += 8; vb0 < nvb; vb0 += 8) {
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        w.template tile_mma<true>(vb0, acc00, acc01, acc10, acc11, o00, o01, o10, o11, prev_v0);
+        o00 = acc00; o01 = acc01; o10 = acc10; o11 = acc11;
+        prev_v0 = vb0 * 32;
+    }
+    store_quads<0, 4, true>(w.tile, o00, o01, o10, o11, prev_v0, w.vg_n, w.lk, w.col);
+}
+
+bool split_table_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128; }
+int split_bank_blocks(int V) { return 2 * ((V + 63) / 64); }                          // 32-row blocks, even
+size_t split_bank_bytes(int V, int C) { return (size_t)SG_NP * split_bank_blocks(V) * 32 * C * 2; }
+
+void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_t st) {
+    const int nvb = split_bank_blocks(V);
+    const int n = nvb * (C / 16) * 64;
+    hipLaunchKernelGGL(split_bank_kernel, dim3((n + 255) / 256), dim3(256), 0, st, memory, (uint4*)frag, V, C, nvb);
+}
+
+template <int NKS>
+static void launch_split_nks(const void* frag, const float* feat, float* table, int V, int HW, int B, int npt, hipStream_t st) {
+    constexpr int lds = SG_NP * SG_PT * (NKS * 16 * 2 + 16);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)split_table_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(split_table_kernel<NKS>, dim3((unsigned)(npt * B)), dim3(SG_THREADS), lds, st, (const uint4*)frag, feat,
+                       table, V, split_bank_blocks(V), HW, npt);
+}
+
+int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st) {
+    const int npt = (HW + SG_PT - 1) / SG_PT;
+    if ((long long)npt * B > 0x7FFFFFFFLL) return -1;
+    switch (C / 16) {
+        case 1: launch_split_nks<1>(frag, feat, table, V, HW, B, npt, st); break;
+        case 2: launch_split_nks<2>(frag, feat, table, V, HW, B, npt, st); break;
+        case 4: launch_split_nks<4>(frag, feat, table, V, HW, B, npt, st); break;
+        case 8: launch_split_nks<8>(frag, feat, table, V, HW, B, npt, st); break;
+        default: return -2;
+    }
     return 0;
 }
 

@@ -172,24 +172,44 @@ def grid_score(pre_rendered, feature_map, clutter_score_map=None):
     return loss, amin, mn
 
 
+TABLE_TILE = 128
+
+
+def table_shape(mesh, B, HW):
+    """Shape of the similarity table of B images: [B, ceil(HW/128), ceil(V/4), 128, 4]
+    (pixel tile, vertex group, pixel in tile, vertex in group)."""
+    return (B, (HW + TABLE_TILE - 1) // TABLE_TILE, (mesh.V + 3) // 4, TABLE_TILE, 4)
+
+
+def table_dense(table, V, HW):
+    """The table as [B, V, HW] (a copy; for inspection and tests)."""
+    B, npt, vg, T, four = table.shape
+    return table.permute(0, 2, 4, 1, 3).reshape(B, vg * four, npt * T)[:, :V, :HW].contiguous()
+
+
 def similarity_table(mesh, feature_map, out=None):
-    """feature_map [B,C,H,W] -> table [B,V,H*W]."""
+    """feature_map [B,C,H,W] -> table [B, ceil(HW/128), ceil(V/4), 128, 4]
+    (element (b,v,p) at [b, p // 128, v // 4, p % 128, v % 4]; padding entries are zero)."""
     lib = _lib.load()
     fm = f32c(feature_map)
     B, Cc, H, W = fm.shape
     if Cc != mesh.C:
         raise ValueError(f"feature map has {Cc} channels, vertex memory has {mesh.C}")
     if out is None:
-        out = torch.empty(B, mesh.V, H * W, device=fm.device)
+        out = torch.empty(table_shape(mesh, B, H * W), device=fm.device)
+    elif tuple(out.shape) != table_shape(mesh, B, H * W) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("out must be a contiguous float32 tensor of shape table_shape(mesh, B, H * W)")
     with torch.cuda.device(fm.device):
         check(lib.nemo_similarity_table(mesh.h, ptr(fm), B, H * W, ptr(out), stream_ptr()), "nemo_similarity_table")
     return out
 
 
 def vertex_similarity(mesh, table, clu, H, W, boxes=None):
-    """table [B,V,HW], clu [B,H,W], boxes [B,4] int32 (r0,r1,c0,c1) or None -> [B]."""
+    """table from similarity_table, clu [B,H,W], boxes [B,4] int32 (r0,r1,c0,c1) or None -> [B]."""
     lib = _lib.load()
     B = table.shape[0]
+    if tuple(table.shape) != table_shape(mesh, B, H * W) or not table.is_contiguous():
+        raise ValueError("table does not match the mesh and map size")
     out = torch.empty(B, device=table.device)
     bx = None if boxes is None else boxes.to(device=table.device, dtype=torch.int32).contiguous()
     with torch.cuda.device(table.device):
@@ -230,7 +250,7 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
     if h2i is not None and h2i.numel() and (int(h2i.min()) < 0 or int(h2i.max()) >= n_img):
         raise ValueError("hyp_to_image out of range")
     clu2 = f32c(clu).reshape(n_img, -1)
-    if tuple(table.shape) != (n_img, mesh.V, cam.H * cam.W) or clu2.shape[1] != cam.H * cam.W:
+    if tuple(table.shape) != table_shape(mesh, n_img, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
         raise ValueError("table / clutter shapes do not match the mesh and camera")
     opt = NemoAdam(int(steps), int(lr_every if lr_every is not None else max(steps // 3, 0)), float(lr), float(betas[0]),
                    float(betas[1]), float(eps), float(lr_gamma))

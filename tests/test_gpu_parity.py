@@ -110,8 +110,13 @@ def test_similarity_table(full):
     fm, _ = sc.feature_maps(2)
     tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
     ref = torch.einsum("vc,bcp->bvp", sc.mem.double(), fm.reshape(2, sc.C, -1).double())
-    assert tab.shape == (2, sc.verts.shape[0], sc.H * sc.W)
-    assert float((tab.double().cpu() - ref).abs().max()) < 1e-5
+    assert tuple(tab.shape) == ops.table_shape(sc.mod.mesh, 2, sc.H * sc.W)
+    V = sc.verts.shape[0]
+    dense = ops.table_dense(tab, V, sc.H * sc.W)
+    assert dense.shape == (2, V, sc.H * sc.W)
+    assert float((dense.double().cpu() - ref).abs().max()) < 1e-6
+    # padding (pixels past HW, vertices past V) is zero: the whole table sums to the dense part
+    assert abs(float(tab.double().abs().sum()) - float(dense.double().abs().sum())) < 1e-6
     # fast_inference similarity on the whole map and on a box
     clu = R.clutter_score(fm, sc.clutter)
     boxes = torch.tensor([[0, sc.H, 0, sc.W], [10, 50, 20, 90]], dtype=torch.int32)
