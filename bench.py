@@ -95,12 +95,12 @@ def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 2: 64)")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="independent batches in flight on separate HIP streams (a 64-image solve launch occupies 64 of "
-                         "the 256 CUs; more batches in flight fill the rest)")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="batches processed together (a 64-image solve launch occupies 64 of the 256 CUs; four batches "
+                         "in flight fill the chip); every batch keeps its own loss normaliser")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -128,37 +128,47 @@ def main():
     B = args.batch
     fm, gts = synthetic_images(mod, clutter, B, first_seed=rank * B, dev=dev)
     cam = mod.camera()
-    S = max(1, args.streams)
-    tables = [torch.empty(ops.table_shape(mod.mesh, B, H * W), device=dev) for _ in range(S)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    gathered = [torch.empty(B, 7, device=dev) for _ in range(world)] if world > 1 else None
+    G = max(1, args.in_flight)
+    # G batches of B images are in flight together: their kernels are launched once over G*B images
+    # (every batch keeps its own loss normaliser B), so that a 300-step solve launch has G*B workgroups
+    # for the 256 CUs instead of B.
+    fm_g = fm.repeat(G, 1, 1, 1) if G > 1 else fm
+    table = torch.empty(ops.table_shape(mod.mesh, G * B, H * W), device=dev)
+    gathered = [torch.empty(G * B, 7, device=dev) for _ in range(world)] if world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}
 
-    def one_batch(timed, slot=0, host_out=None):
-        table = tables[slot]
+    def one_group(g, timed=False, host_out=None):
+        """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major)."""
+        n = g * B
+        x = fm_g[:n]
         if timed:
             ev[0].record()
-        clu = ops.clutter_score(fm, clutter)
+        clu = ops.clutter_score(x, clutter)
         if timed:
             ev[1].record()
-        _, idx, _ = ops.grid_score(pre, fm, clu)
+        _, idx, _ = ops.grid_score(pre, x, clu)
         idx = idx.long()
         if timed:
             ev[2].record()
-        ops.similarity_table(mod.mesh, fm, out=table)
+        tab = ops.similarity_table(mod.mesh, x, out=table[:n])
         if timed:
             ev[3].record()
-        pose, _ = ops.solve(mod.mesh, cam, table, clu, cs[idx], ths[idx], global_batch=B * world, dof=3, steps=EPOCHS,
+        pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], global_batch=B * world, dof=3, steps=EPOCHS,
                             lr=0.05, betas=(0.4, 0.6), lr_gamma=0.2, lr_every=EPOCHS // 3)
         if timed:
             ev[4].record()
         sph = ops.spherical_angles(pose[:, 0:3])
         res = torch.cat([sph[:, 2:3], sph[:, 1:2], pose[:, 3:4], sph[:, 0:1], pose[:, 4:7]], dim=1)   # az, el, th, d, px, py, score
         if world > 1:
-            dist.all_gather(gathered, res.contiguous())
-            res = torch.cat(gathered)
-        if host_out is not None:                    # the [B,7] result goes to (pinned) host memory per batch
+            if g == G:
+                dist.all_gather(gathered, res.contiguous())
+                res = torch.cat(gathered)
+            else:
+                part = [torch.empty(n, 7, device=dev) for _ in range(world)]
+                dist.all_gather(part, res.contiguous())
+                res = torch.cat(part)
+        if host_out is not None:                    # the results go to (pinned) host memory per group
             host_out.copy_(res, non_blocking=True)
         return res
 
@@ -167,30 +177,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # un-timed: per-kernel durations of one batch at a time (HIP events on the launch stream)
-    n_probe = max(2, args.warmup)
+    # un-timed: per-kernel durations of one group (HIP events on the launch stream), then the warm-up batches
+    n_probe = 3
     for i in range(n_probe):
-        res = one_batch(True)
+        one_group(G, timed=True)
         torch.cuda.current_stream().synchronize()
         if i > 0:
             for j, k in enumerate(list(kern_ms)):
                 kern_ms[k] += ev[j].elapsed_time(ev[j + 1]) / (n_probe - 1)
-    for i in range(args.warmup):
-        with torch.cuda.stream(streams[i % S]):
-            one_batch(False, i % S)
-    host_res = torch.empty(args.steps, B * world, 7).pin_memory()
+    done = 0
+    while done < args.warmup:
+        g = min(G, args.warmup - done)
+        one_group(g)
+        done += g
+    groups = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
+    host_res = [torch.empty(world * g * B, 7).pin_memory() for g in groups]
     sync()
-    # timed: exactly `steps` batches, up to S in flight; every batch's result is copied to the host
+    # timed: exactly `steps` batches of B images per GPU, G at a time; every result is copied to the host
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        slot = i % S
-        with torch.cuda.stream(streams[slot]):
-            one_batch(False, slot, host_res[i])
-    for st in streams:
-        st.synchronize()
+    for g, out in zip(groups, host_res):
+        one_group(g, host_out=out)
     sync()
     elapsed = time.perf_counter() - t0
-    res = host_res[args.steps - 1]
+    res = host_res[0][:B]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -205,7 +214,7 @@ def main():
         med_err = sorted(errs)[len(errs) // 2] * 180 / math.pi
         n_hyp_steps = args.steps * B * world * EPOCHS
         solve_ms = kern_ms["solve"]
-        achieved = B * EPOCHS * ALGO_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9
+        achieved = G * B * EPOCHS * ALGO_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -215,13 +224,13 @@ def main():
                                    "80x100x128 feature maps, cuboid mesh V=1118 F=1904, 144-pose pre-rendered grid scoring + "
                                    "300 Adam steps per image, random-init vertex bank",
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": int(pre.shape[0]), "adam_steps": EPOCHS,
-                       "streams": S,
+                       "batches_in_flight": G,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
-            "kernel_ms_per_batch": dict(kern_ms), "batches_in_flight": S,
+            "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
             "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "achieved = 300 steps x B hypotheses x 4.128 MB (one read of the image's feature map + clutter "
+                         "note": "achieved = 300 steps x hypotheses per launch x 4.128 MB (one read of the image's feature map + clutter "
                                  "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
                                  "kernel reads a precomputed vertex x pixel similarity table instead (3 floats per covered pixel), "
                                  "so frac > 1 means it beats the streaming roofline; see DESIGN.md"},

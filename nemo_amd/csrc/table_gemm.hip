@@ -7,17 +7,17 @@
 //
 // Two kernels:
 //
-//  * split_table_kernel (the one used when C is a multiple of 16 and <= 128): every f32 operand is
-//    written as a sum of three bf16 pieces x = h + m + l (each piece the round-to-nearest bf16 of what
-//    the previous ones left over, so the three carry 24 mantissa bits), and the product is
-//    accumulated in f32 by v_mfma_f32_32x32x16_bf16 over the six piece pairs whose weight is
-//    >= 2^-16 relative: hh, hm, mh, hl, lh, mm.  The dropped pairs are below f32 resolution; the
-//    result is as close to the exact dot product as an f32 fma chain is (measured: smaller rms
-//    error than an f32 matmul), at 6/16 of the f32 matrix-core cost (the bf16 pipe has 16 x
-//    the rate of the f32 pipe), so the six products are 2.7 x faster and the kernel becomes bound by writing
-//    the table to HBM.  The vertex bank is split once per nemo_mesh_set_memory into MFMA fragment
-//    order; the feature tile of a workgroup (128 pixels x C channels) is split once into LDS and
-//    reused for every vertex block.
+//  * split_table_kernel (C = 16, 32, 64 or 128): every f32 operand, scaled by a power of two into the
+//    comfortable part of the f16 range, is written as a sum of two f16 pieces x = h + l (l the
+//    round-to-nearest f16 of what h left over: 22 significant bits together), and the product is
+//    accumulated in f32 by v_mfma_f32_32x32x16_f16 over the three piece pairs hh, hl, lh.  The dropped
+//    pair ll is below f32 resolution; measured against an f64 product the result has the rms error of
+//    an f32 matmul.  The f16 pipe has 16 x the rate of the f32 pipe, so the three products cost 3/16 of
+//    the f32 matrix-core time and the kernel is bound by writing the table to HBM.  The vertex bank is
+//    split once per nemo_mesh_set_memory into MFMA fragment order; the feature tile of a workgroup
+//    (128 pixels x C channels) is split once into LDS and reused for every vertex block.  Features are
+//    unit vectors per pixel by the reference's contract (F.normalize in the backbone wrapper); a
+//    component of magnitude above 255.8 would leave the f16 range after scaling and is clamped.
 //
 //  * table_gemm_kernel (any C): v_mfma_f32_32x32x2_f32, an exact f32 fma chain over c.  Both
 //    operands are read "k-major": A = memory^T [C, V] (the transpose is kept by the mesh handle)
@@ -145,60 +145,79 @@ int launch_table_gemm(const float* memT, const float* feat, float* table, int V,
 
 
 // ---------------------------------------------------------------------------------------------
-// split-bf16 path
+// split-f16 path
 // ---------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));     // 8 bf16 bit patterns (one MFMA operand fragment)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));     // one MFMA operand fragment
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SG_NP = 3;            // bf16 pieces per f32 value
+constexpr int SG_NP = 2;            // f16 pieces per f32 value
 constexpr int SG_PT = 128;          // pixels per workgroup
-constexpr int SG_THREADS = 512;     // 8 waves: 4 (vertex blocks of 64) x 2 (pixel blocks of 64)
+constexpr int SG_THREADS = 256;     // 4 waves: 2 (vertex blocks of 64) x 2 (pixel blocks of 64)
+constexpr float SG_FEAT_SCALE = 256.0f;         // features are unit vectors per pixel: scaled values stay far inside f16
+constexpr float SG_FEAT_LIMIT = 65504.0f;       // largest finite f16: scaled features beyond it are clamped
 
-// Round-to-nearest-even bf16 pair of two finite floats, packed lo | hi << 16.
-__device__ inline uint32_t pack_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+// x (already scaled) -> h = f16(x), l = f16(x - h), both round-to-nearest-even; x - h is exact in f32.
+// h + l carries 22 significant bits of x, and h*h' + h*l' + l*h' accumulated in f32 reproduces x*x' to
+// a few 1e-7 relative, the accuracy of an f32 multiply-add chain.
+__device__ inline void split2(float x0, float x1, uint32_t* h, uint32_t* l) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    union { f16x2 v; uint32_t u; } ph, pl;
+    ph.v = (f16x2){h0, h1}; pl.v = (f16x2){l0, l1};
+    *h = ph.u; *l = pl.u;
 }
 
-// Split 8 floats into SG_NP x 8 bf16 pieces: out[piece] holds the 8 values' piece as 4 packed dwords.
 __device__ inline void split8(const float x[8], uint4 out[SG_NP]) {
-    float r[8];
+    uint32_t h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = x[j];
-#pragma unroll
-    for (int pc = 0; pc < SG_NP; ++pc) {
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            w[j] = pack_bf16(r[2 * j], r[2 * j + 1]);
-            if (pc + 1 < SG_NP) {          // remainders are exact in f32
-                r[2 * j] -= __uint_as_float(w[j] << 16);
-                r[2 * j + 1] -= __uint_as_float(w[j] & 0xFFFF0000u);
-            }
-        }
-        out[pc] = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int j = 0; j < 4; ++j) split2(x[2 * j], x[2 * j + 1], &h[j], &l[j]);
+    out[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    out[1] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// Header of the bank fragment buffer (first 256 bytes): largest |memory| as float bits, the power-of-two
+// scale applied to the bank, and the factor that undoes both scales on the result.
+struct BankMeta { uint32_t absmax_bits; float scale; float unscale; };
+constexpr size_t SG_META_BYTES = 256;
+
+__global__ void bank_absmax_kernel(const float* __restrict__ memory, size_t n, BankMeta* meta) {
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(memory[i]);
+        if (a < __builtin_inff()) m = fmaxf(m, a);       // NaN / inf do not pick the scale
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&meta->absmax_bits, __float_as_uint(m));
 }
 
 // Vertex bank -> MFMA A-operand fragments: frag[((piece * nvb + vb) * nks + ks) * 64 + lane] holds
-// rows vb*32 + (lane & 31), channels ks*16 + 8*(lane >> 5) .. +7; rows >= V are zero.
-__global__ void split_bank_kernel(const float* __restrict__ memory, uint4* __restrict__ frag, int V, int C, int nvb) {
+// rows vb*32 + (lane & 31), channels ks*16 + 8*(lane >> 5) .. +7; rows >= V are zero.  The bank is
+// scaled by the power of two that brings its largest magnitude into [128, 256).
+__global__ void split_bank_kernel(const float* __restrict__ memory, BankMeta* meta, uint4* __restrict__ frag, int V, int C,
+                                  int nvb) {
+    const float amax = __uint_as_float(meta->absmax_bits);
+    int e = 0;
+    if (amax > 0.0f) { (void)frexpf(amax, &e); e = 8 - e; }            // amax * 2^e in [128, 256)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    const float scale = ldexpf(1.0f, e);
     const int nks = C / 16;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { meta->scale = scale; meta->unscale = ldexpf(1.0f, -e) / SG_FEAT_SCALE; }
     if (i >= nvb * nks * 64) return;
     const int lane = i & 63, ks = (i >> 6) % nks, vb = (i >> 6) / nks;
     const int row = vb * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = row < V ? memory[(size_t)row * C + k0 + j] : 0.0f;
+    for (int j = 0; j < 8; ++j) x[j] = row < V ? memory[(size_t)row * C + k0 + j] * scale : 0.0f;
     uint4 pcs[SG_NP];
     split8(x, pcs);
 #pragma unroll
     for (int pc = 0; pc < SG_NP; ++pc) frag[((size_t)(pc * nvb + vb) * nks + ks) * 64 + lane] = pcs[pc];
 }
 
-__device__ inline bf16x8 as_frag(const uint4& u) {
-    union { uint4 u; bf16x8 f; } c; c.u = u; return c.f;
+__device__ inline f16x8 as_frag(const uint4& u) {
+    union { uint4 u; f16x8 f; } c; c.u = u; return c.f;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -210,17 +229,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // rows exist, and the stores are straight-line code.
 template <int J0, int J1, bool CHECK>
 __device__ inline void store_quads(f32x4* __restrict__ tile, const f32x16& c00, const f32x16& c01, const f32x16& c10,
-                                   const f32x16& c11, int v0, int vg_n, int lk, int col) {
+                                   const f32x16& c11, int v0, int vg_n, int lk, int col, float us) {
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
         const int g0 = (v0 >> 2) + 2 * j + lk, g1 = g0 + 8;
         if (!CHECK || g0 < vg_n) {
-            __builtin_nontemporal_store((f32x4){c00[4 * j], c00[4 * j + 1], c00[4 * j + 2], c00[4 * j + 3]}, tile + g0 * SG_PT + col);
-            __builtin_nontemporal_store((f32x4){c01[4 * j], c01[4 * j + 1], c01[4 * j + 2], c01[4 * j + 3]}, tile + g0 * SG_PT + col + 32);
+            __builtin_nontemporal_store((f32x4){c00[4 * j] * us, c00[4 * j + 1] * us, c00[4 * j + 2] * us, c00[4 * j + 3] * us}, tile + g0 * SG_PT + col);
+            __builtin_nontemporal_store((f32x4){c01[4 * j] * us, c01[4 * j + 1] * us, c01[4 * j + 2] * us, c01[4 * j + 3] * us}, tile + g0 * SG_PT + col + 32);
         }
         if (!CHECK || g1 < vg_n) {
-            __builtin_nontemporal_store((f32x4){c10[4 * j], c10[4 * j + 1], c10[4 * j + 2], c10[4 * j + 3]}, tile + g1 * SG_PT + col);
-            __builtin_nontemporal_store((f32x4){c11[4 * j], c11[4 * j + 1], c11[4 * j + 2], c11[4 * j + 3]}, tile + g1 * SG_PT + col + 32);
+            __builtin_nontemporal_store((f32x4){c10[4 * j] * us, c10[4 * j + 1] * us, c10[4 * j + 2] * us, c10[4 * j + 3] * us}, tile + g1 * SG_PT + col);
+            __builtin_nontemporal_store((f32x4){c11[4 * j] * us, c11[4 * j + 1] * us, c11[4 * j + 2] * us, c11[4 * j + 3] * us}, tile + g1 * SG_PT + col + 32);
         }
     }
 }
@@ -228,7 +247,7 @@ __device__ inline void store_quads(f32x4* __restrict__ tile, const f32x16& c00, 
 template <int NKS>
 struct SplitWave {
     const uint4* bank_frag; const char* bbase; f32x4* tile;
-    size_t apiece; int vg_n, lane, lk, col;
+    size_t apiece; int vg_n, lane, lk, col; float unscale;
     static constexpr int C = NKS * 16;
     static constexpr int row_bytes = C * 2 + 16;      // +16: consecutive pixels start 4 banks apart
     static constexpr int piece_bytes = SG_PT * row_bytes;
@@ -237,7 +256,7 @@ struct SplitWave {
     template <int KS>
     __device__ inline void store_slice(const f32x16& o00, const f32x16& o01, const f32x16& o10, const f32x16& o11, int v0) const {
         constexpr int J0 = KS * QPK < 4 ? KS * QPK : 4, J1 = (KS + 1) * QPK < 4 ? (KS + 1) * QPK : 4;
-        store_quads<J0, J1, false>(tile, o00, o01, o10, o11, v0, vg_n, lk, col);
+        store_quads<J0, J1, false>(tile, o00, o01, o10, o11, v0, vg_n, lk, col, unscale);
     }
 
     // One 64 x 64 result tile (vertex blocks vb0, vb0 + 1).  The A fragments of k-step ks+1 are requested
@@ -252,17 +271,12 @@ struct SplitWave {
         const uint4* a1p = a0p + (size_t)NKS * 64;
         uint4 na0[SG_NP], na1[SG_NP];
 #pragma unroll
-#ifdef TG_NOALOAD
-        for (int pc = 0; pc < SG_NP; ++pc) { na0[pc] = make_uint4(lane, pc, vb0, 3); na1[pc] = make_uint4(lane, pc + 5, vb0, 7); }
-#else
         for (int pc = 0; pc < SG_NP; ++pc) { na0[pc] = a0p[pc * apiece]; na1[pc] = a1p[pc * apiece]; }
-#endif
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            bf16x8 a0[SG_NP], a1[SG_NP], b0[SG_NP], b1[SG_NP];
+            f16x8 a0[SG_NP], a1[SG_NP], b0[SG_NP], b1[SG_NP];
 #pragma unroll
             for (int pc = 0; pc < SG_NP; ++pc) { a0[pc] = as_frag(na0[pc]); a1[pc] = as_frag(na1[pc]); }
-#ifndef TG_NOALOAD
             if (ks + 1 < NKS) {
 #pragma unroll
                 for (int pc = 0; pc < SG_NP; ++pc) {
@@ -270,17 +284,12 @@ struct SplitWave {
                     na1[pc] = a1p[pc * apiece + (size_t)(ks + 1) * 64];
                 }
             }
-#endif
 #pragma unroll
             for (int pc = 0; pc < SG_NP; ++pc) {
                 b0[pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + ks * 32));
                 b1[pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + 32 * row_bytes + ks * 32));
             }
-#ifdef TG_NOSTORE
-            if (STORE_PREV && o00[0] == 12345.678f) {
-#else
             if (STORE_PREV) {
-#endif
                 switch (ks) {          // ks is a compile-time constant after unrolling
                     case 0: store_slice<0>(o00, o01, o10, o11, prev_v0); break;
                     case 1: store_slice<1>(o00, o01, o10, o11, prev_v0); break;
@@ -292,15 +301,14 @@ struct SplitWave {
                     default: store_slice<7>(o00, o01, o10, o11, prev_v0); break;
                 }
             }
-            // piece pairs in increasing weight: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            // piece pairs in increasing weight: (l,h) (h,l) (h,h)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int ia = q == 0 ? 2 : q == 1 ? 0 : q == 2 ? 1 : q == 3 ? 1 : 0;
-                const int ib = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : q == 3 ? 0 : q == 4 ? 1 : 0;
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ia], b0[ib], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ia], b1[ib], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ia], b0[ib], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ia], b1[ib], acc11, 0, 0, 0);
+            for (int q = 0; q < 3; ++q) {
+                const int ia = q == 0 ? 1 : 0, ib = q == 1 ? 1 : 0;
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ia], b0[ib], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ia], b1[ib], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ia], b0[ib], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ia], b1[ib], acc11, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);        // keep the k-steps apart: registers for one step's operands only
         }
@@ -309,9 +317,10 @@ struct SplitWave {
 
 // NKS = C / 16 k-steps, fully unrolled.
 template <int NKS>
-__global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const uint4* __restrict__ bank_frag,
-                                                                 const float* __restrict__ feat, float* __restrict__ table,
-                                                                 int V, int nvb, int HW, int npt) {
+__global__ __launch_bounds__(SG_THREADS, 2) void split_table_kernel(const BankMeta* __restrict__ meta,
+                                                                    const uint4* __restrict__ bank_frag,
+                                                                    const float* __restrict__ feat, float* __restrict__ table,
+                                                                    int V, int nvb, int HW, int npt) {
     extern __shared__ __align__(16) char sg_lds[];
     using W = SplitWave<NKS>;
     constexpr int C = W::C, row_bytes = W::row_bytes, piece_bytes = W::piece_bytes;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const uint4* __
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* fb = feat + (size_t)b * C * HW;
 
-    // ---- phase 1: feature tile -> bf16 pieces in LDS, [piece][pixel][channel] ----
+    // ---- phase 1: feature tile -> f16 pieces in LDS, [piece][pixel][channel] ----
     {
         const int pl = t & (SG_PT - 1);
         const int p = p0 + pl;
@@ -340,10 +349,9 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const uint4* __
         for (int it = 0; it < NIT; ++it) {
             const int kg = t / SG_PT + it * KG_STEP;
             if (kg < NKG) {
-                if (!pok) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x[it][j] = 0.0f;
-                }
+                for (int j = 0; j < 8; ++j)
+                    x[it][j] = pok ? fminf(fmaxf(x[it][j] * SG_FEAT_SCALE, -SG_FEAT_LIMIT), SG_FEAT_LIMIT) : 0.0f;
                 uint4 pcs[SG_NP];
                 split8(x[it], pcs);
 #pragma unroll
@@ -355,8 +363,9 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const uint4* __
     __syncthreads();
 
     // ---- phase 2: all vertex blocks against the resident pixel tile ----
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;          // wr in 0..1
     W w;
+    w.unscale = meta->unscale;
     w.bank_frag = bank_frag; w.lane = lane; w.lk = lane >> 5;
     w.bbase = sg_lds + (wc * 64 + (lane & 31)) * row_bytes + w.lk * 16;
     w.vg_n = (V + 3) >> 2;
@@ -376,27 +385,33 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const uint4* __
         o00 = acc00; o01 = acc01; o10 = acc10; o11 = acc11;
     }
     int prev_v0 = vb0 * 32;
-    for (vb0 += 8; vb0 < nvb; vb0 += 8) {
+    for (vb0 += 4; vb0 < nvb; vb0 += 4) {
         f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
         w.template tile_mma<true>(vb0, acc00, acc01, acc10, acc11, o00, o01, o10, o11, prev_v0);
         o00 = acc00; o01 = acc01; o10 = acc10; o11 = acc11;
         prev_v0 = vb0 * 32;
     }
-    store_quads<0, 4, true>(w.tile, o00, o01, o10, o11, prev_v0, w.vg_n, w.lk, w.col);
+    store_quads<0, 4, true>(w.tile, o00, o01, o10, o11, prev_v0, w.vg_n, w.lk, w.col, w.unscale);
 }
 
 bool split_table_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128; }
 int split_bank_blocks(int V) { return 2 * ((V + 63) / 64); }                          // 32-row blocks, even
-size_t split_bank_bytes(int V, int C) { return (size_t)SG_NP * split_bank_blocks(V) * 32 * C * 2; }
+size_t split_bank_bytes(int V, int C) { return SG_META_BYTES + (size_t)SG_NP * split_bank_blocks(V) * 32 * C * 2; }
 
-void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_t st) {
+void launch_split_bank(const float* memory, void* buf, int V, int C, hipStream_t st) {
+    BankMeta* meta = (BankMeta*)buf;
+    uint4* frag = (uint4*)((char*)buf + SG_META_BYTES);
     const int nvb = split_bank_blocks(V);
     const int n = nvb * (C / 16) * 64;
-    hipLaunchKernelGGL(split_bank_kernel, dim3((n + 255) / 256), dim3(256), 0, st, memory, (uint4*)frag, V, C, nvb);
+    (void)hipMemsetAsync(meta, 0, SG_META_BYTES, st);
+    hipLaunchKernelGGL(bank_absmax_kernel, dim3(64), dim3(256), 0, st, memory, (size_t)V * C, meta);
+    hipLaunchKernelGGL(split_bank_kernel, dim3((n + 255) / 256), dim3(256), 0, st, memory, meta, frag, V, C, nvb);
 }
 
 template <int NKS>
-static void launch_split_nks(const void* frag, const float* feat, float* table, int V, int HW, int B, int npt, hipStream_t st) {
+static void launch_split_nks(const void* buf, const float* feat, float* table, int V, int HW, int B, int npt, hipStream_t st) {
+    const BankMeta* meta = (const BankMeta*)buf;
+    const uint4* frag = (const uint4*)((const char*)buf + SG_META_BYTES);
     constexpr int lds = SG_NP * SG_PT * (NKS * 16 * 2 + 16);
     static bool attr_done[64] = {};
     int dev = 0;
@@ -405,8 +420,8 @@ static void launch_split_nks(const void* frag, const float* feat, float* table, 
         (void)hipFuncSetAttribute((const void*)split_table_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(split_table_kernel<NKS>, dim3((unsigned)(npt * B)), dim3(SG_THREADS), lds, st, (const uint4*)frag, feat,
-                       table, V, split_bank_blocks(V), HW, npt);
+    hipLaunchKernelGGL(split_table_kernel<NKS>, dim3((unsigned)(npt * B)), dim3(SG_THREADS), lds, st, meta, frag, feat, table, V,
+                       split_bank_blocks(V), HW, npt);
 }
 
 int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st) {
