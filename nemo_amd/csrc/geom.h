@@ -177,6 +177,30 @@ __device__ inline void eval_and_min(int face, const FaceVerts& f, int p, float x
     atomicMin(&zbuf[p], depth_key(pz, face));
 }
 
+// Coverage test and depth-buffer update for the optimisation loop, all three depths positive.  Same
+// decision and the same depth as eval_and_min up to a few ulp (reciprocal instead of division,
+// contracted multiply-adds, the common factor 1/area dropped), at a fifth of the instructions: with
+// u_i = e_i * z_j * z_k the corrected barycentrics are u_i / sum(u), the pixel is inside when the three
+// edge functions share a sign, and the depth is z0 z1 z2 (e0 + e1 + e2) / sum(u).  Only the images
+// rendered for callers need the bit-exact rule; here a pixel centre within rounding distance of an
+// edge may fall on either side.
+#pragma clang fp contract(fast)
+__device__ inline void eval_and_min_fast(int face, const FaceVerts& f, int p, float xf, float yf, unsigned long long* zbuf) {
+    const float dx0 = xf - f.x0, dy0 = yf - f.y0, dx1 = xf - f.x1, dy1 = yf - f.y1, dx2 = xf - f.x2, dy2 = yf - f.y2;
+    const float e0 = dx1 * (f.y2 - f.y1) - dy1 * (f.x2 - f.x1);
+    const float e1 = dx2 * (f.y0 - f.y2) - dy2 * (f.x0 - f.x2);
+    const float e2 = dx0 * (f.y1 - f.y0) - dy0 * (f.x1 - f.x0);
+    const bool pos = e0 > 0.0f && e1 > 0.0f && e2 > 0.0f;
+    const bool neg = e0 < 0.0f && e1 < 0.0f && e2 < 0.0f;
+    if (!(pos || neg)) return;
+    const float z12 = f.z1 * f.z2;
+    const float su = e0 * z12 + f.z0 * (e1 * f.z2 + e2 * f.z1);
+    const float pz = (f.z0 * z12) * ((e0 + e1) + e2) * __builtin_amdgcn_rcpf(su);
+    if (!(pz >= 0.0f)) return;
+    atomicMin(&zbuf[p], depth_key(pz, face));
+}
+#pragma clang fp contract(off)
+
 // ------------------------------------------------------------------------------------------
 // Backward.  Per covered pixel the gradient of the loss w.r.t. the three barycentrics (gb) is
 // pushed through the perspective correction and the edge functions to the NDC position and depth

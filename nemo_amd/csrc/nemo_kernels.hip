@@ -153,12 +153,12 @@ extern "C" int nemo_mesh_info(nemo_mesh_t m, int32_t* V, int32_t* F, int32_t* C)
 // ------------------------------------------------------------------------------------------
 // LDS plan of the rasterising kernels (layout and front end: raster.h)
 // ------------------------------------------------------------------------------------------
-static int plan_layout(int H, int W, int V, int F, LdsLayout* L) {
+static int plan_layout(int H, int W, int V, int F, int threads, LdsLayout* L) {
     if (H > kMaxSide || W > kMaxSide || F >= kMaxFaces)
         return fail(NEMO_ERR_UNSUPPORTED, "map %dx%d / %d faces exceed the rasteriser's limits (%d x %d pixels, %d faces)", H, W, F,
                     kMaxSide, kMaxSide, kMaxFaces - 1);
-    *L = make_layout(H, W, V, F, true);
-    if (L->total > kMaxLds) *L = make_layout(H, W, V, F, false);
+    *L = make_layout(H, W, V, F, true, threads / 64);
+    if (L->total > kMaxLds) *L = make_layout(H, W, V, F, false, threads / 64);
     if (L->total > kMaxLds)
         return fail(NEMO_ERR_UNSUPPORTED,
                     "map %dx%d with %d vertices needs %d bytes of LDS per workgroup (limit %d)", H, W, V,
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kRasterThreads) void render_kernel(RenderArgs a) {
     }
     __syncthreads();
     project_vertices(a.rc, s);
-    raster_faces<FL>(a.rc, s);
+    raster_faces<FL, true>(a.rc, s);
     for (int p = threadIdx.x; p < HW; p += blockDim.x) {
         unsigned long long key = s.zbuf[p];
         int f = -1;
@@ -285,7 +285,7 @@ extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* c
     RenderArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, &a.rc.L);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kRasterThreads, &a.rc.L);
     if (rcode) return rcode;
     a.memory_t = m->memory_t; a.C = m->C;
     a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderB
     }
     __syncthreads();
     project_vertices(a.rc, s);
-    raster_faces<FL>(a.rc, s);
+    raster_faces<FL, true>(a.rc, s);
     unsigned int* seg;
     const int cnt = compact_covered(a.rc, s, &seg);
     PixelGrad acc;
@@ -370,7 +370,7 @@ extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const
     RenderBwdArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, &a.rc.L);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kRasterThreads, &a.rc.L);
     if (rcode) return rcode;
     a.memory_t = m->memory_t; a.C = m->C;
     a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
@@ -667,7 +667,7 @@ struct SolveArgs {
 };
 
 template <bool FL>
-__global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
     const int h = blockIdx.x, tid = threadIdx.x;
@@ -731,15 +731,20 @@ __global__ __launch_bounds__(kRasterThreads) void solve_kernel(SolveArgs a) {
         STAMP(0);
         project_vertices(a.rc, s);
         STAMP(1);
-        raster_pass1<FL>(a.rc, s);
+        raster_direct<FL>(a.rc, s);
 #ifdef NEMO_STAMPS_P1
         if (tid == 0 && a.out_hist) for (int k = 0; k < 3; ++k) a.out_hist[(size_t)h * a.steps + 8 + k] += s.tot[k] / (float)a.steps;
 #endif
         STAMP(7);
-        raster_pass2<FL>(a.rc, s);
+#ifdef NEMO_STAMPS_P1
+        if (tid == 0 && a.out_hist) { a.out_hist[(size_t)h * a.steps + 11] += (float)s.qcount[0] / (float)a.steps; a.out_hist[(size_t)h * a.steps + 12] += (float)s.qcount[1] / (float)a.steps; }
+#endif
         STAMP(2);
         unsigned int* seg;
         const int cnt = compact_covered(a.rc, s, &seg);
+#ifdef NEMO_STAMPS_P1
+        if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
+#endif
         STAMP(3);
 
         float vals[16];
@@ -855,7 +860,7 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     SolveArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, &a.rc.L);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kSolveThreads, &a.rc.L);
     if (rcode) return rcode;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_principal;
@@ -869,7 +874,7 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     a.out_pose = out_pose; a.out_hist = out_hist;
     auto kern = a.rc.L.faces >= 0 ? solve_kernel<true> : solve_kernel<false>;
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
-    hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

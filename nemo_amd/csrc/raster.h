@@ -27,8 +27,8 @@
 namespace nemo {
 
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kRasterThreads = 512;
-constexpr int kRasterWaves = kRasterThreads / 64;
+constexpr int kRasterThreads = 512;           // render kernels: 2 waves per SIMD, up to 256 registers each
+constexpr int kSolveThreads = 512;            // optimisation kernel (1024 threads would cap it at 128 registers: spills in the serial sections)
 constexpr int kMaxSide = 128;                // queue entry = xi | yi << 7 | face << 14
 constexpr int kPixBits = 14;
 constexpr int kMaxFaces = 1 << (32 - kPixBits);
@@ -48,6 +48,7 @@ struct LdsLayout {
     int queue;                  // u32 [qcap]: pair queue, later the per-wave covered segments
     int qcap;                   // entries
     int seg;                    // entries per wave segment (multiple of 64)
+    int waves;                  // waves of the workgroup the layout is for
     int red;                    // f32 [16 values][16 waves]
     int tot;                    // f32 [16]
     int pc;                     // PoseCam
@@ -57,8 +58,9 @@ struct LdsLayout {
 
 inline int align16(int x) { return (x + 15) & ~15; }
 
-inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
+inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int waves) {
     LdsLayout L;
+    L.waves = waves;
     const int HW = H * W;
     int o = 0;
     L.zbuf = o; o = align16(o + 8 * HW);
@@ -67,8 +69,8 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds) {
     L.xs = o; o = align16(o + 4 * W);
     L.ys = o; o = align16(o + 4 * H);
     const int chunks = (HW + 63) / 64;
-    L.seg = ((chunks + kRasterWaves - 1) / kRasterWaves) * 64;
-    L.qcap = L.seg * kRasterWaves;
+    L.seg = ((chunks + waves - 1) / waves) * 64;
+    L.qcap = L.seg * waves;
     if (L.qcap < 8192) L.qcap = 8192;
     L.queue = o; o = align16(o + 4 * L.qcap);
     L.red = o; o = align16(o + 4 * 16 * 16);
@@ -233,17 +235,25 @@ __device__ inline int wave_inclusive_scan(int v, int* total) {
     return v;
 }
 
-// Exact coverage test of one (face, pixel) pair and depth-buffer update.
+// Coverage test of one (face, pixel) pair and depth-buffer update.  EXACT: the reference's arithmetic
+// bit for bit; otherwise the short form for faces in front of the camera (others take the exact path).
+template <bool EXACT>
 __device__ inline void eval_pair(int face, const FaceVerts& fv, int xi, int yi, int W, const Lds& s) {
     const float xf = s.xs[xi], yf = s.ys[yi];
+    if (!EXACT && fv.z0 > 0.0f && fv.z1 > 0.0f && fv.z2 > 0.0f) {
+        eval_and_min_fast(face, fv, yi * W + xi, xf, yf, s.zbuf);
+        return;
+    }
     const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
     const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
     if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) return;     // exact bounding-box rejection
     eval_and_min(face, fv, yi * W + xi, xf, yf, s.zbuf);
 }
 
+constexpr int kInPlace = 6;
+
 // Key buffer must be empty and s.qcount[0..1] == 0 on entry; ends with a barrier.
-template <bool FACES_LDS>
+template <bool FACES_LDS, bool EXACT>
 __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
     const int H = rc.cc.H, W = rc.cc.W;
     const int half = rc.L.qcap >> 1;
@@ -327,18 +337,40 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
                         if (r < 4) mask_lo |= bits << (r * 8); else mask_hi |= bits << ((r - 4) * 8);
                     }
                 }
-                const int n = __popc(mask_lo) + __popc(mask_hi);
-                cnt_near = near ? n : 0;
-                cnt_far = near ? 0 : n;
             } else {
                 // close-up face: evaluate its box in place (exact path), no queueing
                 for (int jy = jy0; jy < jy0 + ny; ++jy)
-                    for (int jx = jx0; jx < jx0 + nx; ++jx) eval_pair(f, fv, W - 1 - jx, H - 1 - jy, W, s);
+                    for (int jx = jx0; jx < jx0 + nx; ++jx) eval_pair<EXACT>(f, fv, W - 1 - jx, H - 1 - jy, W, s);
             }
         }
+        if (!EXACT) {
+            // The first kInPlace candidates of every face are evaluated right here, while the face is in
+            // registers (short form, pixel centres from the affine approximation); what is left of a
+            // larger face goes through the queue.  The loop ends as soon as no lane of the wave has a
+            // candidate left.
+            const bool inplace = zpos;
+            for (int it = 0; it < kInPlace; ++it) {
+                const bool has = inplace && (mask_lo | mask_hi) != 0u;
+                if (!__any(has)) break;
+                if (has) {
+                    const bool lo_half = mask_lo != 0u;
+                    const unsigned int m = lo_half ? mask_lo : mask_hi;
+                    const int k = __ffs((int)m) - 1;
+                    if (lo_half) mask_lo = m & (m - 1); else mask_hi = m & (m - 1);
+                    const int jx = jx0 + (k & 7), jy = jy0 + (k >> 3) + (lo_half ? 0 : 4);
+                    const float xf = __builtin_fmaf((float)jx, dx, x_org), yf = __builtin_fmaf((float)jy, dy, y_org);
+                    eval_and_min_fast(f, fv, (H - 1 - jy) * W + (W - 1 - jx), xf, yf, s.zbuf);
+                }
+            }
+        }
+        {
+            const int n = __popc(mask_lo) + __popc(mask_hi);
+            cnt_near = near ? n : 0;
+            cnt_far = near ? 0 : n;
+        }
         P1STAMP(1);
-        int total;
-        const int incl = wave_inclusive_scan(cnt_near | (cnt_far << 16), &total);
+        int total = 0, incl = 0;
+        if (EXACT || __any((cnt_near | cnt_far) != 0)) incl = wave_inclusive_scan(cnt_near | (cnt_far << 16), &total);
         if (total) {
             unsigned int bn = 0, bf = 0;
             if ((threadIdx.x & 63) == 0) {
@@ -358,7 +390,7 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
                     m &= m - 1;
                     const int xi = W - 1 - (jx0 + (k & 7)), yi = H - 1 - (jy0 + (k >> 3) + 4 * halfsel);
                     if (slot < (unsigned)half) s.queue[off + slot] = pack_entry(xi, yi, f);
-                    else eval_pair(f, fv, xi, yi, W, s);          // queue half full: evaluate in place
+                    else eval_pair<EXACT>(f, fv, xi, yi, W, s);   // queue half full: evaluate in place
                     ++slot;
                 }
             }
@@ -372,39 +404,170 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
     __syncthreads();
 }
 
-// Ends with a barrier and with both queue counters reset.
+// Rasteriser of the optimisation loop: every face walks the pixel centres of its bounding box with
+// incrementally evaluated edge functions (planes in the affine pixel-centre coordinates) and depth,
+// no queue and no second pass.  Same decisions as the exact rule except for pixel centres within
+// rounding distance (1e-7 of the face's extent) of an edge.  A face is typically 1-2 pixels, a box 2-6
+// centres; the lanes of a wave step through their boxes together and leave the loop when the largest
+// box of the wave is done.  Faces with a vertex behind the camera take the exact rule.
+// Key buffer must be empty on entry; ends with a barrier.
+#pragma clang fp contract(fast)
 template <bool FACES_LDS>
-__device__ inline void raster_pass2(const RasterCtx& rc, const Lds& s) {
+__device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
+    const int H = rc.cc.H, W = rc.cc.W;
+    const float rx = ndc_range(W, H), ry = ndc_range(H, W);
+    const float dx = rx / (float)W, dy = ry / (float)H;
+    const float x_org = -0.5f * rx + 0.5f * dx, y_org = -0.5f * ry + 0.5f * dy;
+    const float inv_dx = (float)W / rx, inv_dy = (float)H / ry;
+#ifdef NEMO_STAMPS_P1
+    long long tq0 = clock64(), tq[4] = {0, 0, 0, 0};
+    int iters = 0;
+#endif
+    // the vertex records of the next face are requested before the pixel walk of the current one
+    FaceVerts nfv = {};
+    {
+        int i0 = 0, i1 = 0, i2 = 0;
+        if ((int)threadIdx.x < rc.F) load_face<FACES_LDS>(rc, s, threadIdx.x, &i0, &i1, &i2);
+        nfv = face_verts(s, i0, i1, i2);
+    }
+    for (int base = 0; base < rc.F; base += blockDim.x) {
+        const int f = base + threadIdx.x;
+        const FaceVerts fv = nfv;
+        {
+            const int fn = f + blockDim.x;
+            int i0 = 0, i1 = 0, i2 = 0;
+            if (fn < rc.F) load_face<FACES_LDS>(rc, s, fn, &i0, &i1, &i2);
+            nfv = face_verts(s, i0, i1, i2);
+        }
+        int n = 0, nx = 1, p = 0;
+        float e0 = 0, e1 = 0, e2 = 0, su = 1, a0 = 0, a1 = 0, a2 = 0, asu = 0, r0 = 0, r1 = 0, r2 = 0, rsu = 0, numer = 0;
+        if (f < rc.F) {
+            const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2);
+            const float farea = edge_fn(fv.x0, fv.y0, fv.x1, fv.y1, fv.x2, fv.y2);
+            bool ok = !(zmax < kEps) && !(farea <= kEps && farea >= -kEps) && (farea == farea);
+            const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
+            const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
+            const float tx0 = (xmin - x_org) * inv_dx - 1e-3f, tx1 = (xmax - x_org) * inv_dx + 1e-3f;
+            const float ty0 = (ymin - y_org) * inv_dy - 1e-3f, ty1 = (ymax - y_org) * inv_dy + 1e-3f;
+            ok = ok && !(tx1 < 0.0f) && !(ty1 < 0.0f) && !(tx0 > (float)(W - 1)) && !(ty0 > (float)(H - 1));
+            const int jx0 = clamp_index(ceilf(tx0), W, 0), jy0 = clamp_index(ceilf(ty0), H, 0);
+            const int jx1 = clamp_index(floorf(tx1), W, W - 1), jy1 = clamp_index(floorf(ty1), H, H - 1);
+            const int bx = jx1 - jx0 + 1, by = jy1 - jy0 + 1;
+            ok = ok && bx > 0 && by > 0;
+            if (ok && !(fv.z0 > 0.0f && fv.z1 > 0.0f && fv.z2 > 0.0f)) {
+                for (int jy = jy0; jy <= jy1; ++jy)
+                    for (int jx = jx0; jx <= jx1; ++jx) eval_pair<true>(f, fv, W - 1 - jx, H - 1 - jy, W, s);
+                ok = false;
+            }
+            if (ok) {
+                nx = bx;
+                n = bx * by;
+                p = (H - 1 - jy0) * W + (W - 1 - jx0);          // pixel of the box origin; flipped indices grow downwards in p
+                const float xo = (float)jx0 * dx + x_org, yo = (float)jy0 * dy + y_org;
+                // e_i(x, y) = (x - xa)(yb - ya) - (y - ya)(xb - xa): value at the origin, step per column, step per row
+                const float A0 = fv.y2 - fv.y1, B0 = fv.x1 - fv.x2;
+                const float A1 = fv.y0 - fv.y2, B1 = fv.x2 - fv.x0;
+                const float A2 = fv.y1 - fv.y0, B2 = fv.x0 - fv.x1;
+                e0 = (xo - fv.x1) * A0 + (yo - fv.y1) * B0;
+                e1 = (xo - fv.x2) * A1 + (yo - fv.y2) * B1;
+                e2 = (xo - fv.x0) * A2 + (yo - fv.y0) * B2;
+                a0 = A0 * dx; a1 = A1 * dx; a2 = A2 * dx;
+                // a row step also rewinds the nx columns walked
+                const float back = (float)nx;
+                r0 = B0 * dy - back * a0; r1 = B1 * dy - back * a1; r2 = B2 * dy - back * a2;
+                // u_i = e_i z_j z_k; corrected barycentrics u_i / sum(u); depth z0 z1 z2 (e0 + e1 + e2) / sum(u)
+                const float z12 = fv.z1 * fv.z2, z02 = fv.z0 * fv.z2, z01 = fv.z0 * fv.z1;
+                su = e0 * z12 + e1 * z02 + e2 * z01;
+                asu = a0 * z12 + a1 * z02 + a2 * z01;
+                rsu = r0 * z12 + r1 * z02 + r2 * z01;
+                numer = (fv.z0 * z12) * ((A0 * (fv.x0 - fv.x1)) + (B0 * (fv.y0 - fv.y1)));   // e0 at vertex 0 = signed area
+            }
+        }
+        P1STAMP(0);
+        // straight-line pixel walk, two centres per trip; the trip count is the largest box of the wave
+        int c = 0;
+        const int row_skip = nx - W;
+        for (int k = 0; __any(k < n); k += 2) {
+#ifdef NEMO_STAMPS_P1
+            ++iters;
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float lo = fminf(fminf(e0, e1), e2), hi = fmaxf(fmaxf(e0, e1), e2);
+                const float pz = numer * __builtin_amdgcn_rcpf(su);
+                if ((lo > 0.0f || hi < 0.0f) && pz >= 0.0f && k + u < n) atomicMin(&s.zbuf[p], depth_key(pz, f));
+                ++c;
+                const bool wrap = c == nx;
+                const float wf = wrap ? 1.0f : 0.0f;
+                e0 = e0 + a0 + wf * r0; e1 = e1 + a1 + wf * r1; e2 = e2 + a2 + wf * r2; su = su + asu + wf * rsu;
+                p = p - 1 + (wrap ? row_skip : 0);
+                c = wrap ? 0 : c;
+            }
+        }
+        P1STAMP(1);
+    }
+#ifdef NEMO_STAMPS_P1
+    if (threadIdx.x == 64) { s.tot[0] = (float)tq[0]; s.tot[1] = (float)tq[1]; s.tot[2] = (float)iters; }
+#endif
+    __syncthreads();
+}
+#pragma clang fp contract(off)
+
+// Evaluates n queued (face, pixel) pairs, kPairBatch per thread at a time so that the dependent LDS
+// reads (entry -> face record -> vertex records) of several pairs are in flight together.  FAR: pairs
+// of the far half, skipped when the face's nearest vertex is clearly behind the depth already stored.
+constexpr int kPairBatch = 2;
+template <bool FACES_LDS, bool EXACT, bool FAR>
+__device__ inline void eval_queue(const RasterCtx& rc, const Lds& s, const unsigned int* q, int n) {
     const int W = rc.cc.W;
+    for (int i0 = threadIdx.x; i0 < n; i0 += kPairBatch * blockDim.x) {
+        int xi[kPairBatch], yi[kPairBatch], f[kPairBatch], v0[kPairBatch], v1[kPairBatch], v2[kPairBatch];
+        bool ok[kPairBatch];
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            const int i = i0 + u * blockDim.x;
+            ok[u] = i < n;
+            unpack_entry(ok[u] ? q[i] : 0u, &xi[u], &yi[u], &f[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) load_face<FACES_LDS>(rc, s, f[u], &v0[u], &v1[u], &v2[u]);
+        FaceVerts fv[kPairBatch];
+        unsigned long long cur[kPairBatch];
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            fv[u] = face_verts(s, v0[u], v1[u], v2[u]);
+            if (FAR) cur[u] = s.zbuf[yi[u] * W + xi[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kPairBatch; ++u) {
+            if (!ok[u]) continue;
+            if (FAR) {
+                // the interpolated depth of a covered pixel is >= zmin * (1 - 5e-7): a face whose nearest
+                // vertex is clearly behind the stored depth cannot win this pixel
+                const float zmin = fminf(fminf(fv[u].z0, fv[u].z1), fv[u].z2);
+                if (cur[u] != kEmptyKey && zmin * 0.999999f > __uint_as_float((unsigned)(cur[u] >> 32))) continue;
+            }
+            eval_pair<EXACT>(f[u], fv[u], xi[u], yi[u], W, s);
+        }
+    }
+}
+
+// Ends with a barrier and with both queue counters reset.
+template <bool FACES_LDS, bool EXACT>
+__device__ inline void raster_pass2(const RasterCtx& rc, const Lds& s) {
     const int half = rc.L.qcap >> 1;
     const int n_near = min((int)s.qcount[0], half), n_far = min((int)s.qcount[1], half);
-    for (int i = threadIdx.x; i < n_near; i += blockDim.x) {
-        int xi, yi, f, i0, i1, i2;
-        unpack_entry(s.queue[i], &xi, &yi, &f);
-        load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
-        eval_pair(f, face_verts(s, i0, i1, i2), xi, yi, W, s);
-    }
+    eval_queue<FACES_LDS, EXACT, false>(rc, s, s.queue, n_near);
     __syncthreads();
-    for (int i = threadIdx.x; i < n_far; i += blockDim.x) {
-        int xi, yi, f, i0, i1, i2;
-        unpack_entry(s.queue[half + i], &xi, &yi, &f);
-        load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
-        const unsigned long long cur = s.zbuf[yi * W + xi];
-        const FaceVerts fv = face_verts(s, i0, i1, i2);
-        // the interpolated depth of a covered pixel is >= zmin * (1 - 5e-7): a face whose nearest vertex
-        // is clearly behind the stored depth cannot win this pixel
-        const float zmin = fminf(fminf(fv.z0, fv.z1), fv.z2);
-        if (cur != kEmptyKey && zmin * 0.999999f > __uint_as_float((unsigned)(cur >> 32))) continue;
-        eval_pair(f, fv, xi, yi, W, s);
-    }
+    eval_queue<FACES_LDS, EXACT, true>(rc, s, s.queue + half, n_far);
     __syncthreads();
     if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
 }
 
-template <bool FACES_LDS>
+template <bool FACES_LDS, bool EXACT>
 __device__ inline void raster_faces(const RasterCtx& rc, const Lds& s) {
-    raster_pass1<FACES_LDS>(rc, s);
-    raster_pass2<FACES_LDS>(rc, s);
+    raster_pass1<FACES_LDS, EXACT>(rc, s);
+    raster_pass2<FACES_LDS, EXACT>(rc, s);
 }
 
 // Each wave compacts the covered pixels of its own chunks (chunk c = 64 consecutive pixels, owned by
@@ -416,7 +579,7 @@ __device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigne
     unsigned int* seg = s.queue + wave * rc.L.seg;
     const float inv_w = 1.0f / (float)rc.cc.W;
     int count = 0;
-    for (int c = wave; c * 64 < HW; c += kRasterWaves) {
+    for (int c = wave; c * 64 < HW; c += rc.L.waves) {
         const int p = c * 64 + lane;
         unsigned long long key = kEmptyKey;
         if (p < HW) key = s.zbuf[p];
