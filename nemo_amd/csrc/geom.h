@@ -74,6 +74,25 @@ __device__ inline void sincos32(float x, float* s, float* c) {
     *s = (float)sd; *c = (float)cd;
 }
 
+// sin and cos in f32 arithmetic, about 1 ulp: Cody-Waite reduction by pi/2 and the Cephes minimax
+// polynomials on [-pi/4, pi/4].  For the optimisation loop, where theta stays within a few turns.
+__device__ inline void sincos_short(float x, float* s, float* c) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = __builtin_fmaf(k, -1.5707962513e+00f, x);
+    r = __builtin_fmaf(k, -7.5497894159e-08f, r);
+    r = __builtin_fmaf(k, -5.3903029534e-15f, r);
+    const float r2 = r * r;
+    const float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    const float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                                    r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k & 3;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    *s = q >= 2 ? -ss : ss;
+    *c = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// EXACT: sin/cos rounded once from f64 (what the rendered images are pinned to); otherwise sincos_short.
+template <bool EXACT = true>
 __device__ inline void pose_setup(const CamConst& cc, const float* C, float theta, float px, float py,
                                   PoseCam* pc) {
     const float up[3] = {0.0f, 1.0f, 0.0f};
@@ -93,7 +112,7 @@ __device__ inline void pose_setup(const CamConst& cc, const float* C, float thet
         pc->degenerate = 1;
     }
     float sn, cs;
-    sincos32(theta, &sn, &cs);
+    if (EXACT) sincos32(theta, &sn, &cs); else sincos_short(theta, &sn, &cs);
     pc->sn = sn; pc->cs = cs;
     for (int i = 0; i < 3; ++i) {
         float r0 = pc->ax[i], r1 = pc->ay[i], r2 = pc->az[i];
@@ -329,6 +348,49 @@ __device__ inline float pixel_score_and_grad(const CamConst& cc, const FaceVerts
         acc->S[0] += gX; acc->S[1] += gY; acc->S[2] += gZ;
         acc->gbx += gxs[i];
         acc->gby += gys[i];
+    }
+    return obj;
+}
+#pragma clang fp contract(off)
+
+// The same forward + backward for the optimisation loop, straight-line and in fewer operations.
+// v_i = (x_ndc, y_ndc, Z, 1/Z) of the face's vertices, all in front of the camera.  With pixel-relative
+// vectors (dx_i, dy_i) = pixel - v_i the edge functions are cross products, e0 = dy1 dx2 - dx1 dy2 ...;
+// u_i = e_i z_j z_k, b_i = u_i / sum(u) (the 1/area factor cancels and is never formed),
+// obj = sum b_i d_i.  Backward: gu_i = g (d_i - obj) / sum(u).  The view-space gradient of a vertex is
+// accumulated through q = Z * gXv = (a gx, a gy, Z gz - a (gx xi + gy eta)) with (xi, eta) = (X/Z, Y/Z):
+// M += (xi, eta, 1)^T (x) q,  S += q / Z.  weight = 1/normaliser for a real entry, 0 for a padding
+// entry (which must still be a valid covered pixel so that every intermediate is finite).
+#pragma clang fp contract(fast)
+__device__ inline float pixel_fused(float a, float ia, float bx, float by, const float4& v0, const float4& v1,
+                                    const float4& v2, float xf, float yf, const float* d, float cl, float weight,
+                                    PixelGrad* acc) {
+    const float dx0 = xf - v0.x, dy0 = yf - v0.y, dx1 = xf - v1.x, dy1 = yf - v1.y, dx2 = xf - v2.x, dy2 = yf - v2.y;
+    const float e0 = dy1 * dx2 - dx1 * dy2, e1 = dy2 * dx0 - dx2 * dy0, e2 = dy0 * dx1 - dx0 * dy1;
+    const float zt0 = v1.z * v2.z, zt1 = v0.z * v2.z, zt2 = v0.z * v1.z;
+    const float u0 = e0 * zt0, u1 = e1 * zt1, u2 = e2 * zt2;
+    const float inv_su = __builtin_amdgcn_rcpf((u0 + u1) + u2);
+    const float obj = ((u0 * d[0] + u1 * d[1]) + u2 * d[2]) * inv_su;
+    const float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+    const float G = -mk * weight * inv_su;
+    const float gu0 = G * (d[0] - obj), gu1 = G * (d[1] - obj), gu2 = G * (d[2] - obj);
+    const float ge0 = gu0 * zt0, ge1 = gu1 * zt1, ge2 = gu2 * zt2;
+    const float h0 = gu0 * e0, h1 = gu1 * e1, h2 = gu2 * e2;
+    const float gz[3] = {h1 * v2.z + h2 * v1.z, h0 * v2.z + h2 * v0.z, h0 * v1.z + h1 * v0.z};
+    const float gx[3] = {ge2 * dy1 - ge1 * dy2, ge0 * dy2 - ge2 * dy0, ge1 * dy0 - ge0 * dy1};
+    const float gy[3] = {ge1 * dx2 - ge2 * dx1, ge2 * dx0 - ge0 * dx2, ge0 * dx1 - ge1 * dx0};
+    const float4 vs[3] = {v0, v1, v2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float xi = (vs[i].x - bx) * ia, eta = (vs[i].y - by) * ia;
+        const float qx = gx[i] * a, qy = gy[i] * a;
+        const float qz = vs[i].z * gz[i] - (qx * xi + qy * eta);
+        acc->M[0] += xi * qx;  acc->M[1] += xi * qy;  acc->M[2] += xi * qz;
+        acc->M[3] += eta * qx; acc->M[4] += eta * qy; acc->M[5] += eta * qz;
+        acc->M[6] += qx;       acc->M[7] += qy;       acc->M[8] += qz;
+        acc->S[0] += qx * vs[i].w; acc->S[1] += qy * vs[i].w; acc->S[2] += qz * vs[i].w;
+        acc->gbx += gx[i];
+        acc->gby += gy[i];
     }
     return obj;
 }

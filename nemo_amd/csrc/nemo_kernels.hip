@@ -726,7 +726,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
 #endif
 
     for (int step = 0; step < a.steps; ++step) {
-        if (tid == 0) pose_setup(a.rc.cc, os->P, os->P[3], os->P[4], os->P[5], s.pc);
+        if (tid == 0) pose_setup<false>(a.rc.cc, os->P, os->P[3], os->P[4], os->P[5], s.pc);
         __syncthreads();
         STAMP(0);
         project_vertices(a.rc, s);
@@ -757,41 +757,37 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             float dmax = 0.0f;      // sum over covered pixels of max(obj, clu) - max(0, clu)
             float dbox = 0.0f;      // the same over the score crop (last step only)
             const ViewInv vinv = view_inv(a.rc.cc, s);
-            // The covered entries of this wave, four per lane at a time: all table / clutter loads of a
-            // batch are issued before any of them is used, so one memory round trip covers the batch.
-            constexpr int UNR = 2;
+            // The covered entries of this wave, UNR per lane at a time, as straight-line code: the LDS
+            // reads, the table / clutter gathers and the arithmetic of the UNR entries interleave.  A lane
+            // whose batch runs past the end re-reads its first entry with weight 0.
+            constexpr int UNR = 3;
+            const float cam_a = a.rc.cc.a;
             for (int ib = tid & 63; ib < cnt; ib += 64 * UNR) {
                 int px[UNR], py[UNR], vi[UNR][3];
-                float dd[UNR][3], cc_[UNR];
-                bool ok[UNR];
+                float dd[UNR][3], cc_[UNR], wg[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int idx = ib + u * 64;
-                    ok[u] = idx < cnt;
+                    const bool ok = idx < cnt;
+                    wg[u] = ok ? 1.0f : 0.0f;
                     int f;
-                    unpack_entry(ok[u] ? seg[idx] : 0u, &px[u], &py[u], &f);
+                    unpack_entry(seg[ok ? idx : ib], &px[u], &py[u], &f);
                     load_face<FL>(a.rc, s, f, &vi[u][0], &vi[u][1], &vi[u][2]);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int p = py[u] * W + px[u];
-                    if (ok[u]) {
-                        dd[u][0] = tab[table_offset(vg_n, vi[u][0], p)];
-                        dd[u][1] = tab[table_offset(vg_n, vi[u][1], p)];
-                        dd[u][2] = tab[table_offset(vg_n, vi[u][2], p)];
-                        cc_[u] = clu[p];
-                    } else { dd[u][0] = dd[u][1] = dd[u][2] = 0.0f; cc_[u] = 0.0f; }
+                    dd[u][0] = tab[table_offset(vg_n, vi[u][0], p)];
+                    dd[u][1] = tab[table_offset(vg_n, vi[u][1], p)];
+                    dd[u][2] = tab[table_offset(vg_n, vi[u][2], p)];
+                    cc_[u] = clu[p];
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    if (!ok[u]) continue;
-                    const int i0 = vi[u][0], i1 = vi[u][1], i2 = vi[u][2];
-                    FaceVerts fv = face_verts(s, i0, i1, i2);
-                    float X0[3], X1[3], X2[3];
-                    view_coords(vinv, fv, X0, X1, X2);
-                    const float obj = pixel_score_and_grad(a.rc.cc, fv, X0, X1, X2, s.xs[px[u]], s.ys[py[u]], dd[u], cc_[u],
-                                                           a.inv_norm, &acc);
-                    const float dlt = fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u]);
+                    const float4 v0 = s.verts[vi[u][0]], v1 = s.verts[vi[u][1]], v2 = s.verts[vi[u][2]];
+                    const float obj = pixel_fused(cam_a, vinv.ia, vinv.bx, vinv.by, v0, v1, v2, s.xs[px[u]], s.ys[py[u]], dd[u],
+                                                  cc_[u], wg[u] * a.inv_norm, &acc);
+                    const float dlt = (fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u])) * wg[u];
                     dmax += dlt;
                     if (last && py[u] >= br0 && py[u] < br1 && px[u] >= bc0 && px[u] < bc1) dbox += dlt;
                 }

@@ -42,7 +42,7 @@ __device__ inline void unpack_entry(unsigned int e, int* xi, int* yi, int* f) {
 
 struct LdsLayout {
     int zbuf;                   // u64 [HW]
-    int verts;                  // float4 [V]: NDC x, NDC y, view depth, unused
+    int verts;                  // float4 [V]: NDC x, NDC y, view depth Z, 1/Z
     int faces;                  // int4 [F]: three vertex indices (or -1: faces are read from global memory)
     int xs, ys;                 // f32 [W], [H]: NDC centre of pixel column xi / row yi
     int queue;                  // u32 [qcap]: pair queue, later the per-wave covered segments
@@ -212,7 +212,7 @@ __device__ inline void project_vertices(const RasterCtx& rc, const Lds& s) {
     for (int v = threadIdx.x; v < rc.V; v += blockDim.x) {
         float Xv[3], xn, yn;
         project_vertex(rc.cc, R, T, bx, by, rc.verts[3 * v], rc.verts[3 * v + 1], rc.verts[3 * v + 2], Xv, &xn, &yn);
-        s.verts[v] = make_float4(xn, yn, Xv[2], 0.0f);
+        s.verts[v] = make_float4(xn, yn, Xv[2], 1.0f / Xv[2]);
     }
     __syncthreads();
 }

@@ -425,7 +425,9 @@ def test_dof6_first_steps_track_oracle(small):
     pose = pose.cpu()
     per_image = torch.stack([h["per_image"] for h in hist], dim=1)
     assert rel_err(lh, per_image) < REL
-    assert rel_err(pose[:, 0:3], Cr) < 1e-4 and float((pose[:, 3] - thr).abs().max()) < 1e-4
+    # theta after six Adam steps from a random start: Adam's normalised update amplifies rounding-level
+    # differences of a small gradient component, so the angle is compared at 1e-3 rad (0.06 degrees)
+    assert rel_err(pose[:, 0:3], Cr) < 1e-4 and float((pose[:, 3] - thr).abs().max()) < 1e-3
     assert float((pose[:, 4:6] - prr).abs().max()) < 1e-3
 
 
