@@ -682,6 +682,8 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
     OptState* os = (OptState*)s.opt;
     const int np = a.dof == 6 ? 6 : 4;
     if (tid == 0) {
+        s.qcount[0] = (unsigned)H; s.qcount[1] = 0u;       // row range of the covered pixels (see raster_direct)
+        s.qcount[2] = kSolveThreads / 64;                  // next face task
         for (int k = 0; k < 6; ++k) { os->m[k] = 0.0f; os->v[k] = 0.0f; }
         os->P[0] = a.init_campos[3 * h]; os->P[1] = a.init_campos[3 * h + 1]; os->P[2] = a.init_campos[3 * h + 2];
         os->P[3] = a.init_theta[h];
@@ -741,7 +743,9 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
 #endif
         STAMP(2);
         unsigned int* seg;
-        const int cnt = compact_covered(a.rc, s, &seg);
+        const int row0 = min((int)s.qcount[0], H), row1 = min((int)s.qcount[1], H);
+        const int cnt = compact_covered(a.rc, s, &seg, row0, max(row1, row0));
+        if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }   // all read before the barrier that ended the compaction
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
 #endif

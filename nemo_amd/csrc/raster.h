@@ -218,6 +218,22 @@ __device__ inline void project_vertices(const RasterCtx& rc, const Lds& s) {
 }
 
 // Inclusive prefix sum of one int per lane over the wave (DPP within 16-lane rows, row totals via readlane).
+// Minimum / maximum of an int over the 64 lanes of a wave; every lane returns the result.
+template <int CTRL>
+__device__ inline int dpp_min(int v) { return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false)); }
+template <int CTRL>
+__device__ inline int dpp_max(int v) { return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false)); }
+__device__ inline int wave_min(int v) {
+    v = dpp_min<0xB1>(v); v = dpp_min<0x4E>(v); v = dpp_min<0x141>(v); v = dpp_min<0x140>(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ inline int wave_max(int v) {
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 template <int CTRL>
 __device__ inline int dpp_shr_add(int v) {
     return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
@@ -408,107 +424,146 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
 // incrementally evaluated edge functions (planes in the affine pixel-centre coordinates) and depth,
 // no queue and no second pass.  Same decisions as the exact rule except for pixel centres within
 // rounding distance (1e-7 of the face's extent) of an edge.  A face is typically 1-2 pixels, a box 2-6
-// centres; the lanes of a wave step through their boxes together and leave the loop when the largest
-// box of the wave is done.  Faces with a vertex behind the camera take the exact rule.
-// Key buffer must be empty on entry; ends with a barrier.
+// centres.  A lane steps two centres of its face per trip, straight-line code; the lanes of a wave leave
+// the loop when the largest box of the wave is done.  Faces with a vertex behind the camera take
+// the exact rule.  Key buffer must be empty on entry; ends with a barrier.
 #pragma clang fp contract(fast)
+struct WalkState {
+    int n, nx, p, c, row_skip, face;
+    float e0, e1, e2, su, a0, a1, a2, asu, r0, r1, r2, rsu, numer;
+};
+
+struct WalkGrid { int H, W; float dx, dy, x_org, y_org, inv_dx, inv_dy; };
+
+// Straight-line: every quantity is computed for every lane and the pixel count n is zeroed for faces
+// that are skipped.  Returns true for a face that needs the exact rule (a vertex behind the camera).
+__device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, const FaceVerts& fv, WalkState* w, int* box) {
+    const int H = g.H, W = g.W;
+    const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2), zmin = fminf(fminf(fv.z0, fv.z1), fv.z2);
+    // signed area = e0 evaluated at vertex 0
+    const float A0 = fv.y2 - fv.y1, B0 = fv.x1 - fv.x2;
+    const float A1 = fv.y0 - fv.y2, B1 = fv.x2 - fv.x0;
+    const float A2 = fv.y1 - fv.y0, B2 = fv.x0 - fv.x1;
+    const float farea = A0 * (fv.x0 - fv.x1) + B0 * (fv.y0 - fv.y1);
+    bool ok = valid && !(zmax < kEps) && (fabsf(farea) > kEps);            // false for NaN
+    const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
+    const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
+    const float tx0 = (xmin - g.x_org) * g.inv_dx - 1e-3f, tx1 = (xmax - g.x_org) * g.inv_dx + 1e-3f;
+    const float ty0 = (ymin - g.y_org) * g.inv_dy - 1e-3f, ty1 = (ymax - g.y_org) * g.inv_dy + 1e-3f;
+    // fmaxf / fminf drop NaNs; a NaN box is rejected through farea
+    const int jx0 = (int)fminf(fmaxf(ceilf(tx0), 0.0f), (float)(W - 1)), jy0 = (int)fminf(fmaxf(ceilf(ty0), 0.0f), (float)(H - 1));
+    const int jx1 = (int)fminf(fmaxf(floorf(tx1), -1.0f), (float)(W - 1)), jy1 = (int)fminf(fmaxf(floorf(ty1), -1.0f), (float)(H - 1));
+    const int bx = jx1 - jx0 + 1, by = jy1 - jy0 + 1;
+    ok = ok && bx > 0 && by > 0 && tx0 <= (float)(W - 1) && ty0 <= (float)(H - 1);
+    const bool slow = ok && !(zmin > 0.0f);
+    box[0] = jx0; box[1] = jy0; box[2] = jx1; box[3] = jy1;
+    w->face = f;
+    w->nx = bx;
+    w->n = (ok && !slow) ? bx * by : 0;
+    w->row_skip = bx - W;
+    w->c = 0;
+    w->p = (H - 1 - jy0) * W + (W - 1 - jx0);          // pixel of the box origin; flipped indices grow downwards in p
+    const float xo = (float)jx0 * g.dx + g.x_org, yo = (float)jy0 * g.dy + g.y_org;
+    // e_i(x, y) = (x - xa)(yb - ya) - (y - ya)(xb - xa): value at the origin, step per column, step per row
+    w->e0 = (xo - fv.x1) * A0 + (yo - fv.y1) * B0;
+    w->e1 = (xo - fv.x2) * A1 + (yo - fv.y2) * B1;
+    w->e2 = (xo - fv.x0) * A2 + (yo - fv.y0) * B2;
+    w->a0 = A0 * g.dx; w->a1 = A1 * g.dx; w->a2 = A2 * g.dx;
+    // a row step also rewinds the nx columns walked
+    const float back = (float)bx;
+    w->r0 = B0 * g.dy - back * w->a0; w->r1 = B1 * g.dy - back * w->a1; w->r2 = B2 * g.dy - back * w->a2;
+    // u_i = e_i z_j z_k; corrected barycentrics u_i / sum(u); depth z0 z1 z2 (e0 + e1 + e2) / sum(u)
+    const float z12 = fv.z1 * fv.z2, z02 = fv.z0 * fv.z2, z01 = fv.z0 * fv.z1;
+    w->su = w->e0 * z12 + w->e1 * z02 + w->e2 * z01;
+    w->asu = w->a0 * z12 + w->a1 * z02 + w->a2 * z01;
+    w->rsu = w->r0 * z12 + w->r1 * z02 + w->r2 * z01;
+    w->numer = (fv.z0 * z12) * farea;
+    return slow;
+}
+
+// One pixel centre of the walk: test, depth, key, then step to the next centre (k = index of this centre).
+__device__ inline void walk_step(WalkState& w, int k, unsigned long long* zbuf) {
+    const float lo = fminf(fminf(w.e0, w.e1), w.e2), hi = fmaxf(fmaxf(w.e0, w.e1), w.e2);
+    const float pz = w.numer * __builtin_amdgcn_rcpf(w.su);
+    if ((lo > 0.0f || hi < 0.0f) && pz >= 0.0f && k < w.n) atomicMin(&zbuf[w.p], depth_key(pz, w.face));
+    ++w.c;
+    const bool wrap = w.c == w.nx;
+    const float wf = wrap ? 1.0f : 0.0f;
+    w.e0 = w.e0 + w.a0 + wf * w.r0; w.e1 = w.e1 + w.a1 + wf * w.r1; w.e2 = w.e2 + w.a2 + wf * w.r2;
+    w.su = w.su + w.asu + wf * w.rsu;
+    w.p = w.p - 1 + (wrap ? w.row_skip : 0);
+    w.c = wrap ? 0 : w.c;
+}
+
+// Work is handed out in tasks of 64 consecutive faces (one per lane): a wave starts with task = its
+// index and takes the next one from an LDS counter (s.qcount[2], which the caller keeps at the number
+// of waves between steps), so waves whose faces have small boxes pick up more tasks.
 template <bool FACES_LDS>
 __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
-    const int H = rc.cc.H, W = rc.cc.W;
-    const float rx = ndc_range(W, H), ry = ndc_range(H, W);
-    const float dx = rx / (float)W, dy = ry / (float)H;
-    const float x_org = -0.5f * rx + 0.5f * dx, y_org = -0.5f * ry + 0.5f * dy;
-    const float inv_dx = (float)W / rx, inv_dy = (float)H / ry;
+    WalkGrid g;
+    g.H = rc.cc.H; g.W = rc.cc.W;
+    const float rx = ndc_range(g.W, g.H), ry = ndc_range(g.H, g.W);
+    g.dx = rx / (float)g.W; g.dy = ry / (float)g.H;
+    g.x_org = -0.5f * rx + 0.5f * g.dx; g.y_org = -0.5f * ry + 0.5f * g.dy;
+    g.inv_dx = (float)g.W / rx; g.inv_dy = (float)g.H / ry;
 #ifdef NEMO_STAMPS_P1
     long long tq0 = clock64(), tq[4] = {0, 0, 0, 0};
     int iters = 0;
 #endif
-    // the vertex records of the next face are requested before the pixel walk of the current one
-    FaceVerts nfv = {};
+    const int lane = threadIdx.x & 63;
+    const int ntask = (rc.F + 63) >> 6;
+    int row_lo = g.H, row_hi = -1;              // pixel rows (yi) this thread's faces may touch
+    int task = threadIdx.x >> 6;
+    // the vertex records of the next task are requested before the pixel walk of the current one
+    FaceVerts nfv;
     {
+        const int f = task * 64 + lane;
         int i0 = 0, i1 = 0, i2 = 0;
-        if ((int)threadIdx.x < rc.F) load_face<FACES_LDS>(rc, s, threadIdx.x, &i0, &i1, &i2);
+        if (f < rc.F) load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
         nfv = face_verts(s, i0, i1, i2);
     }
-    for (int base = 0; base < rc.F; base += blockDim.x) {
-        const int f = base + threadIdx.x;
+    while (task < ntask) {
+        const int f = task * 64 + lane;
         const FaceVerts fv = nfv;
+        unsigned int nt = 0;
+        if (lane == 0) nt = atomicAdd(&s.qcount[2], 1u);
+        const int next = (int)__builtin_amdgcn_readfirstlane(nt);
         {
-            const int fn = f + blockDim.x;
+            const int fn = next * 64 + lane;
             int i0 = 0, i1 = 0, i2 = 0;
             if (fn < rc.F) load_face<FACES_LDS>(rc, s, fn, &i0, &i1, &i2);
             nfv = face_verts(s, i0, i1, i2);
         }
-        int n = 0, nx = 1, p = 0;
-        float e0 = 0, e1 = 0, e2 = 0, su = 1, a0 = 0, a1 = 0, a2 = 0, asu = 0, r0 = 0, r1 = 0, r2 = 0, rsu = 0, numer = 0;
-        if (f < rc.F) {
-            const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2);
-            const float farea = edge_fn(fv.x0, fv.y0, fv.x1, fv.y1, fv.x2, fv.y2);
-            bool ok = !(zmax < kEps) && !(farea <= kEps && farea >= -kEps) && (farea == farea);
-            const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
-            const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
-            const float tx0 = (xmin - x_org) * inv_dx - 1e-3f, tx1 = (xmax - x_org) * inv_dx + 1e-3f;
-            const float ty0 = (ymin - y_org) * inv_dy - 1e-3f, ty1 = (ymax - y_org) * inv_dy + 1e-3f;
-            ok = ok && !(tx1 < 0.0f) && !(ty1 < 0.0f) && !(tx0 > (float)(W - 1)) && !(ty0 > (float)(H - 1));
-            const int jx0 = clamp_index(ceilf(tx0), W, 0), jy0 = clamp_index(ceilf(ty0), H, 0);
-            const int jx1 = clamp_index(floorf(tx1), W, W - 1), jy1 = clamp_index(floorf(ty1), H, H - 1);
-            const int bx = jx1 - jx0 + 1, by = jy1 - jy0 + 1;
-            ok = ok && bx > 0 && by > 0;
-            if (ok && !(fv.z0 > 0.0f && fv.z1 > 0.0f && fv.z2 > 0.0f)) {
-                for (int jy = jy0; jy <= jy1; ++jy)
-                    for (int jx = jx0; jx <= jx1; ++jx) eval_pair<true>(f, fv, W - 1 - jx, H - 1 - jy, W, s);
-                ok = false;
-            }
-            if (ok) {
-                nx = bx;
-                n = bx * by;
-                p = (H - 1 - jy0) * W + (W - 1 - jx0);          // pixel of the box origin; flipped indices grow downwards in p
-                const float xo = (float)jx0 * dx + x_org, yo = (float)jy0 * dy + y_org;
-                // e_i(x, y) = (x - xa)(yb - ya) - (y - ya)(xb - xa): value at the origin, step per column, step per row
-                const float A0 = fv.y2 - fv.y1, B0 = fv.x1 - fv.x2;
-                const float A1 = fv.y0 - fv.y2, B1 = fv.x2 - fv.x0;
-                const float A2 = fv.y1 - fv.y0, B2 = fv.x0 - fv.x1;
-                e0 = (xo - fv.x1) * A0 + (yo - fv.y1) * B0;
-                e1 = (xo - fv.x2) * A1 + (yo - fv.y2) * B1;
-                e2 = (xo - fv.x0) * A2 + (yo - fv.y0) * B2;
-                a0 = A0 * dx; a1 = A1 * dx; a2 = A2 * dx;
-                // a row step also rewinds the nx columns walked
-                const float back = (float)nx;
-                r0 = B0 * dy - back * a0; r1 = B1 * dy - back * a1; r2 = B2 * dy - back * a2;
-                // u_i = e_i z_j z_k; corrected barycentrics u_i / sum(u); depth z0 z1 z2 (e0 + e1 + e2) / sum(u)
-                const float z12 = fv.z1 * fv.z2, z02 = fv.z0 * fv.z2, z01 = fv.z0 * fv.z1;
-                su = e0 * z12 + e1 * z02 + e2 * z01;
-                asu = a0 * z12 + a1 * z02 + a2 * z01;
-                rsu = r0 * z12 + r1 * z02 + r2 * z01;
-                numer = (fv.z0 * z12) * ((A0 * (fv.x0 - fv.x1)) + (B0 * (fv.y0 - fv.y1)));   // e0 at vertex 0 = signed area
-            }
+        WalkState w;
+        int box[4];
+        const bool slow = walk_setup(g, f, f < rc.F, fv, &w, box);
+        if (w.n > 0 || slow) { row_lo = min(row_lo, g.H - 1 - box[3]); row_hi = max(row_hi, g.H - 1 - box[1]); }
+        if (__any(slow)) {                       // rare: a face crossing the camera plane
+            if (slow)
+                for (int jy = box[1]; jy <= box[3]; ++jy)
+                    for (int jx = box[0]; jx <= box[2]; ++jx) eval_pair<true>(f, fv, g.W - 1 - jx, g.H - 1 - jy, g.W, s);
         }
         P1STAMP(0);
-        // straight-line pixel walk, two centres per trip; the trip count is the largest box of the wave
-        int c = 0;
-        const int row_skip = nx - W;
-        for (int k = 0; __any(k < n); k += 2) {
+        for (int k = 0; __any(k < w.n); k += 2) {
 #ifdef NEMO_STAMPS_P1
             ++iters;
 #endif
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float lo = fminf(fminf(e0, e1), e2), hi = fmaxf(fmaxf(e0, e1), e2);
-                const float pz = numer * __builtin_amdgcn_rcpf(su);
-                if ((lo > 0.0f || hi < 0.0f) && pz >= 0.0f && k + u < n) atomicMin(&s.zbuf[p], depth_key(pz, f));
-                ++c;
-                const bool wrap = c == nx;
-                const float wf = wrap ? 1.0f : 0.0f;
-                e0 = e0 + a0 + wf * r0; e1 = e1 + a1 + wf * r1; e2 = e2 + a2 + wf * r2; su = su + asu + wf * rsu;
-                p = p - 1 + (wrap ? row_skip : 0);
-                c = wrap ? 0 : c;
-            }
+            walk_step(w, k, s.zbuf);
+            walk_step(w, k + 1, s.zbuf);
         }
         P1STAMP(1);
+        task = next;
     }
 #ifdef NEMO_STAMPS_P1
     if (threadIdx.x == 64) { s.tot[0] = (float)tq[0]; s.tot[1] = (float)tq[1]; s.tot[2] = (float)iters; }
 #endif
+    // rows that can hold covered pixels: s.qcount[0] = first, s.qcount[1] = last + 1 (the caller keeps
+    // them at H and 0 between steps)
+    row_lo = wave_min(row_lo); row_hi = wave_max(row_hi);
+    if (lane == 0 && row_hi >= row_lo) {
+        atomicMin(&s.qcount[0], (unsigned)row_lo);
+        atomicMax(&s.qcount[1], (unsigned)(row_hi + 1));
+    }
     __syncthreads();
 }
 #pragma clang fp contract(off)
@@ -573,25 +628,36 @@ __device__ inline void raster_faces(const RasterCtx& rc, const Lds& s) {
 // Each wave compacts the covered pixels of its own chunks (chunk c = 64 consecutive pixels, owned by
 // wave c % 16) into its segment of the queue area and resets the key buffer.  Returns the number of
 // entries in this wave's segment (pack_entry format).  Ends with a barrier.
-__device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigned int** seg_out) {
+__device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigned int** seg_out, int row0 = 0, int row1 = -1) {
     const int HW = rc.cc.H * rc.cc.W;
+    if (row1 < 0) row1 = rc.cc.H;
+    const int c0 = (row0 * rc.cc.W) >> 6, c1 = (row1 * rc.cc.W + 63) >> 6;      // chunks holding rows [row0, row1)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int* seg = s.queue + wave * rc.L.seg;
     const float inv_w = 1.0f / (float)rc.cc.W;
     int count = 0;
-    for (int c = wave; c * 64 < HW; c += rc.L.waves) {
-        const int p = c * 64 + lane;
-        unsigned long long key = kEmptyKey;
-        if (p < HW) key = s.zbuf[p];
-        const bool cov = key != kEmptyKey;
-        if (cov) s.zbuf[p] = kEmptyKey;
-        const unsigned long long m = __ballot(cov);
-        if (cov) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            const int yi = (int)(((float)p + 0.5f) * inv_w);       // exact for p < 2^22
-            seg[count + rank] = pack_entry(p - yi * rc.cc.W, yi, (int)(key & 0xFFFFFFFFull));
+    constexpr int CB = 4;                       // chunks in flight per wave: their key reads overlap
+    for (int cb = c0 + wave; cb < c1; cb += CB * rc.L.waves) {
+        unsigned long long key[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int c = cb + u * rc.L.waves;
+            const int p = c * 64 + lane;
+            key[u] = (c < c1 && p < HW) ? s.zbuf[p] : kEmptyKey;
         }
-        count += __popcll(m);
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int p = (cb + u * rc.L.waves) * 64 + lane;
+            const bool cov = key[u] != kEmptyKey;
+            const unsigned long long m = __ballot(cov);
+            if (cov) {
+                s.zbuf[p] = kEmptyKey;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                const int yi = (int)(((float)p + 0.5f) * inv_w);       // exact for p < 2^22
+                seg[count + rank] = pack_entry(p - yi * rc.cc.W, yi, (int)(key[u] & 0xFFFFFFFFull));
+            }
+            count += __popcll(m);
+        }
     }
     __syncthreads();
     *seg_out = seg;
