@@ -176,6 +176,30 @@ int nemo_solve(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, con
                const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
                const nemo_adam* opt, float* out_pose, float* out_loss_hist, void* stream);
 
+/* ---- keypoint-initialised solver (nemo/models/solve_pose.py) ----------------------------------
+ * get_corr_pytorch (solve_pose.py:27-82) on the similarity table of ONE image:
+ *   corr[i,a,b] = sum_v vis[i,v] * table[v, pixel(round((kp[i,v] + (px[a], py[b])) / down_sample_rate))]
+ * where a keypoint counts only if the rounded pixel satisfies 0 <= x < W-1 and 0 <= y < H-1 (the
+ * reference's bounds), round = half to even, and kp + sample is the f64 sum rounded to f32 (the
+ * reference adds the f64 sample to the f32 tensor in place).
+ * kp_coords [n_pose,V,2] f32, kp_vis [n_pose,V] f32, px/py samples f64 (device), out [n_pose,n_px,n_py]. */
+int nemo_keypoint_corr(nemo_mesh_t mesh, const float* table, const float* kp_coords, const float* kp_vis,
+                       const double* px_samples, const double* py_samples, int32_t n_pose, int32_t n_px,
+                       int32_t n_py, float down_sample_rate, int32_t H, int32_t W, float* out, void* stream);
+
+/* The per-proposal Adam loop of solve_pose.solve_pose (solve_pose.py:220-324): like nemo_solve, but
+ * the translation is the reference's 2-D flow: the map rendered at the camera's own principal point
+ * is resampled bilinearly at pixel + flow / translation_scale (flow_warp.py:6-46: grid_sample,
+ * align_corners=True, border padding) before the comparison with the image.  Parameters: C, theta and,
+ * when optimize_translation != 0, the flow.  init_flow [n_hyp,2] (NULL: zero).  out_pose [n_hyp,8] as
+ * nemo_solve with columns 4,5 = the flow.  Every proposal of an image is one hypothesis
+ * (hyp_to_image), so the reference's sequential loop over proposals becomes one launch. */
+int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, const float* clu,
+                    const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
+                    const float* init_flow, int32_t n_hyp, int32_t n_img, int32_t global_batch,
+                    int32_t optimize_translation, float translation_scale, const nemo_adam* opt,
+                    float* out_pose, float* out_loss_hist, void* stream);
+
 /* camera_position_to_spherical_angle (nemo/utils/mesh.py:50-56) on device:
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */
 int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream);

@@ -17,7 +17,7 @@ SYMBOLS = [
     "nemo_last_error", "nemo_version", "nemo_mesh_create", "nemo_mesh_set_memory", "nemo_mesh_destroy",
     "nemo_mesh_info", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
     "nemo_grid_score_workspace", "nemo_grid_score", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
-    "nemo_solve", "nemo_spherical_angles",
+    "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
 ]
 
 
@@ -63,11 +63,14 @@ def load():
     lib.nemo_vertex_similarity.argtypes = [vp, f32p, f32p, vp, i32, i32, i32, f32p, vp]
     lib.nemo_solve.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, f32p, f32p, f32p, vp, i32, i32, i32, i32,
                                C.POINTER(NemoAdam), f32p, f32p, vp]
+    lib.nemo_keypoint_corr.argtypes = [vp, f32p, f32p, f32p, vp, vp, i32, i32, i32, C.c_float, i32, i32, f32p, vp]
+    lib.nemo_solve_flow.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, f32p, f32p, f32p, i32, i32, i32, i32, C.c_float,
+                                    C.POINTER(NemoAdam), f32p, f32p, vp]
     lib.nemo_align_maps.argtypes = [f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, vp]
     lib.nemo_spherical_angles.argtypes = [f32p, i32, f32p, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("nemo_last_error", "nemo_version", "nemo_grid_score_workspace"):
+        if name not in ("nemo_last_error", "nemo_version", "nemo_grid_score_workspace", "nemo_similarity_table_elems"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -396,6 +396,16 @@ __device__ inline float pixel_fused(float a, float ia, float bx, float by, const
 }
 #pragma clang fp contract(off)
 
+// Forward only: the interpolated score sum b_i d_i of a pixel centre inside (or on the rim of) a face.
+#pragma clang fp contract(fast)
+__device__ inline float pixel_score(const float4& v0, const float4& v1, const float4& v2, float xf, float yf, const float* d) {
+    const float dx0 = xf - v0.x, dy0 = yf - v0.y, dx1 = xf - v1.x, dy1 = yf - v1.y, dx2 = xf - v2.x, dy2 = yf - v2.y;
+    const float e0 = dy1 * dx2 - dx1 * dy2, e1 = dy2 * dx0 - dx2 * dy0, e2 = dy0 * dx1 - dx0 * dy1;
+    const float u0 = e0 * (v1.z * v2.z), u1 = e1 * (v0.z * v2.z), u2 = e2 * (v0.z * v1.z);
+    return ((u0 * d[0] + u1 * d[1]) + u2 * d[2]) * __builtin_amdgcn_rcpf((u0 + u1) + u2);
+}
+#pragma clang fp contract(off)
+
 // From the reduced sums to the gradient of (C[3], theta, px, py).
 __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, const float* M, const float* S, float gbx,
                                      float gby, float* gC, float* gtheta, float* gpx, float* gpy) {

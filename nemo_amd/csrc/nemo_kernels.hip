@@ -660,13 +660,17 @@ struct SolveArgs {
     const float* init_campos; const float* init_theta; const float* init_principal;
     const int32_t* score_boxes;
     float def_px, def_py;
+    float tscale, inv_tscale;    // warp mode: the reference's translation_scale (flow units per pixel) and its inverse
     int n_img; float inv_norm; int dof;
     int steps, lr_every;
     double lr, beta1, beta2, eps, gamma;
     float* out_pose; float* out_hist;
 };
 
-template <bool FL>
+// WARP: the keypoint-initialised solver's translation model (solve_pose.py:258-276): parameters 4, 5 are a
+// 2-D flow; the map rendered at the default principal point is resampled bilinearly at pixel + flow / scale
+// (flow_warp.py: grid_sample, align_corners=True, border padding) before it is compared with the image.
+template <bool FL, bool WARP>
 __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
@@ -687,8 +691,8 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         for (int k = 0; k < 6; ++k) { os->m[k] = 0.0f; os->v[k] = 0.0f; }
         os->P[0] = a.init_campos[3 * h]; os->P[1] = a.init_campos[3 * h + 1]; os->P[2] = a.init_campos[3 * h + 2];
         os->P[3] = a.init_theta[h];
-        os->P[4] = a.init_principal ? a.init_principal[2 * h] : a.def_px;
-        os->P[5] = a.init_principal ? a.init_principal[2 * h + 1] : a.def_py;
+        os->P[4] = a.init_principal ? a.init_principal[2 * h] : (WARP ? 0.0f : a.def_px);
+        os->P[5] = a.init_principal ? a.init_principal[2 * h + 1] : (WARP ? 0.0f : a.def_py);
         os->lr = a.lr; os->b1p = 1.0; os->b2p = 1.0;
         os->first_loss = 0.0f; os->last_loss = 0.0f;
     }
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
 #endif
 
     for (int step = 0; step < a.steps; ++step) {
-        if (tid == 0) pose_setup<false>(a.rc.cc, os->P, os->P[3], os->P[4], os->P[5], s.pc);
+        if (tid == 0) pose_setup<false>(a.rc.cc, os->P, os->P[3], WARP ? a.def_px : os->P[4], WARP ? a.def_py : os->P[5], s.pc);
         __syncthreads();
         STAMP(0);
         project_vertices(a.rc, s);
@@ -742,17 +746,87 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         if (tid == 0 && a.out_hist) { a.out_hist[(size_t)h * a.steps + 11] += (float)s.qcount[0] / (float)a.steps; a.out_hist[(size_t)h * a.steps + 12] += (float)s.qcount[1] / (float)a.steps; }
 #endif
         STAMP(2);
+        float vals[16];
+        const bool last = step == a.steps - 1;
+        const int row0 = min((int)s.qcount[0], H), row1 = max(min((int)s.qcount[1], H), row0);
+        if (WARP) {
+            // Target-centred pass over the whole map: a target pixel blends the scores of its four source
+            // pixels in the rendered map; the gradient flows back to every covered source's face and to
+            // the flow itself.  (One image at a time and a handful of proposals: simplicity over speed.)
+            // Sample positions in torch's own float arithmetic (flow_warp.py + grid_sample, align_corners=True):
+            // normalised grid = linspace(-1, 1, n)[i] + (flow / scale) / ((n - 1) / 2), pixel = ((g + 1) / 2) (n - 1).
+            // With a zero or whole-pixel flow the position lands within an ulp of a pixel centre, where the
+            // bilinear surface has a kink: which one-sided slope the flow gradient sees is decided by this
+            // rounding, in the reference as here.
+            const float tscale = a.tscale;
+            const float fnx = (os->P[4] / tscale) / (((float)W - 1.0f) / 2.0f), fny = (os->P[5] / tscale) / (((float)H - 1.0f) / 2.0f);
+            const float stepx = 2.0f / (float)(W - 1), stepy = 2.0f / (float)(H - 1);
+            __syncthreads();                    // everyone has read the row range and the flow
+            if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }
+            PixelGrad acc;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
+            acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
+            float dmax = 0.0f, dbox = 0.0f, gfx = 0.0f, gfy = 0.0f;
+            const ViewInv vinv = view_inv(a.rc.cc, s);
+            const float cam_a = a.rc.cc.a;
+            for (int pt = tid; pt < HW; pt += blockDim.x) {
+                const int yt = pt / W, xt = pt - yt * W;
+                const float lx = xt < W / 2 ? -1.0f + stepx * (float)xt : 1.0f - stepx * (float)(W - 1 - xt);
+                const float ly = yt < H / 2 ? -1.0f + stepy * (float)yt : 1.0f - stepy * (float)(H - 1 - yt);
+                const float fxr = (((lx + fnx) + 1.0f) / 2.0f) * (float)(W - 1), fyr = (((ly + fny) + 1.0f) / 2.0f) * (float)(H - 1);
+                const float fx = fminf(fmaxf(fxr, 0.0f), (float)(W - 1)), fy = fminf(fmaxf(fyr, 0.0f), (float)(H - 1));
+                const bool x_free = fxr > 0.0f && fxr < (float)(W - 1), y_free = fyr > 0.0f && fyr < (float)(H - 1);
+                const float x0f = floorf(fx), y0f = floorf(fy);
+                const float ax = fx - x0f, ay = fy - y0f;
+                const int x0 = (int)x0f, y0 = (int)y0f, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+                const int qx[4] = {x0, x1, x0, x1}, qy[4] = {y0, y0, y1, y1};
+                const float wq[4] = {(1.0f - ax) * (1.0f - ay), ax * (1.0f - ay), (1.0f - ax) * ay, ax * ay};
+                unsigned long long key[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) key[k] = s.zbuf[qy[k] * W + qx[k]];
+                if (key[0] == kEmptyKey && key[1] == kEmptyKey && key[2] == kEmptyKey && key[3] == kEmptyKey) continue;
+                const float cl = clu[pt];
+                float sk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float dd[4][3];
+                int vi[4][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (key[k] == kEmptyKey) continue;      // a source of weight 0 still enters the flow gradient
+                    load_face<FL>(a.rc, s, (int)(key[k] & 0xFFFFFFFFull), &vi[k][0], &vi[k][1], &vi[k][2]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) dd[k][i] = tab[table_offset(vg_n, vi[k][i], pt)];
+                    sk[k] = pixel_score(s.verts[vi[k][0]], s.verts[vi[k][1]], s.verts[vi[k][2]], s.xs[qx[k]], s.ys[qy[k]], dd[k]);
+                }
+                const float obj = (wq[0] * sk[0] + wq[1] * sk[1]) + (wq[2] * sk[2] + wq[3] * sk[3]);
+                const float dlt = fmaxf(obj, cl) - fmaxf(0.0f, cl);
+                dmax += dlt;
+                if (last && yt >= br0 && yt < br1 && xt >= bc0 && xt < bc1) dbox += dlt;
+                const float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+                if (mk == 0.0f) continue;
+                const float g = -mk * a.inv_norm;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (key[k] == kEmptyKey || wq[k] == 0.0f) continue;
+                    (void)pixel_fused(cam_a, vinv.ia, vinv.bx, vinv.by, s.verts[vi[k][0]], s.verts[vi[k][1]], s.verts[vi[k][2]],
+                                      s.xs[qx[k]], s.ys[qy[k]], dd[k], -__builtin_inff(), mk * a.inv_norm * wq[k], &acc);
+                }
+                if (x_free) gfx += g * ((1.0f - ay) * (sk[1] - sk[0]) + ay * (sk[3] - sk[2]));
+                if (y_free) gfy += g * ((1.0f - ax) * (sk[2] - sk[0]) + ax * (sk[3] - sk[1]));
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) vals[i] = acc.M[i];
+            vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2];
+            vals[12] = gfx * a.inv_tscale; vals[13] = gfy * a.inv_tscale; vals[14] = dmax; vals[15] = dbox;
+        } else {
         unsigned int* seg;
-        const int row0 = min((int)s.qcount[0], H), row1 = min((int)s.qcount[1], H);
-        const int cnt = compact_covered(a.rc, s, &seg, row0, max(row1, row0));
+        const int cnt = compact_covered(a.rc, s, &seg, row0, row1);
         if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }   // all read before the barrier that ended the compaction
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
 #endif
         STAMP(3);
 
-        float vals[16];
-        const bool last = step == a.steps - 1;
         {
             PixelGrad acc;
 #pragma unroll
@@ -801,9 +875,12 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2];
             vals[12] = acc.gbx; vals[13] = acc.gby; vals[14] = dmax; vals[15] = dbox;
         }
+        }
         STAMP(4);
         block_sum<16>(vals, s.red, s.tot);
         STAMP(5);
+        if (WARP)       // the key buffer was not consumed by a compaction: empty the rows that were drawn
+            for (int p = row0 * W + tid; p < row1 * W; p += blockDim.x) s.zbuf[p] = kEmptyKey;
 
         if (tid == 0) {
             float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
@@ -812,6 +889,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
             float g[6];
             pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
+            if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
             // torch.optim.Adam (single-tensor path): lerp for the first moment, mul+addcmul for the
             // second, bias corrections and step size in double, then addcdiv.
             os->b1p *= a.beta1; os->b2p *= a.beta2;
@@ -872,9 +950,88 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     a.steps = opt->steps; a.lr_every = opt->lr_every;
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
     a.out_pose = out_pose; a.out_hist = out_hist;
-    auto kern = a.rc.L.faces >= 0 ? solve_kernel<true> : solve_kernel<false>;
+    a.tscale = 1.0f; a.inv_tscale = 0.0f;
+    auto kern = a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>;
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// Refinement of the keypoint-initialised solver (solve_pose.py:220-324): every proposal of an image is one
+// hypothesis; parameters C, theta and, when optimize_translation is set, the 2-D flow.
+extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+                               const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
+                               const float* init_flow, int32_t n_hyp, int32_t n_img, int32_t global_batch,
+                               int32_t optimize_translation, float translation_scale, const nemo_adam* opt,
+                               float* out_pose, float* out_hist, void* stream) {
+    if (n_hyp == 0) return NEMO_OK;
+    if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_solve_flow: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    if (!(translation_scale > 0.0f)) return fail(NEMO_ERR_INVALID, "nemo_solve_flow: translation_scale must be positive");
+    if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve_flow: negative step count");
+    SolveArgs a;
+    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kSolveThreads, &a.rc.L);
+    if (rcode) return rcode;
+    a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
+    a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_flow;
+    a.score_boxes = nullptr;
+    a.def_px = cam->px; a.def_py = cam->py;
+    a.tscale = translation_scale; a.inv_tscale = 1.0f / translation_scale;
+    a.n_img = n_img;
+    a.inv_norm = 1.0f / ((float)global_batch * (float)(cam->H * cam->W));
+    a.dof = optimize_translation ? 6 : 4;
+    a.steps = opt->steps; a.lr_every = opt->lr_every;
+    a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
+    a.out_pose = out_pose; a.out_hist = out_hist;
+    auto kern = a.rc.L.faces >= 0 ? solve_kernel<true, true> : solve_kernel<false, true>;
+    if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// keypoint correlation (get_corr_pytorch, solve_pose.py:27-82)
+// ------------------------------------------------------------------------------------------
+// corr[i, a, b] = sum_v vis[i, v] * table[v, pixel(round((kp[i, v] + (px[a], py[b])) / dsr))], keypoints that
+// land outside [0, W-1) x [0, H-1) do not count.  One workgroup per (pose i, a, b).
+__global__ __launch_bounds__(256) void keypoint_corr_kernel(const float* __restrict__ table, const float* __restrict__ kp,
+                                                            const float* __restrict__ vis, const double* __restrict__ pxs,
+                                                            const double* __restrict__ pys, int V, int npx, int npy,
+                                                            float dsr, int H, int W, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x % npy, a_ = (blockIdx.x / npy) % npx, i = blockIdx.x / (npx * npy);
+    const double ox = pxs[a_], oy = pys[b];
+    const int vg_n = (V + 3) >> 2;
+    float sum = 0.0f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        // the reference adds the f64 sample to the f32 coordinate in place: f64 sum rounded to f32
+        const float x = (float)((double)kp[((size_t)i * V + v) * 2] + ox), y = (float)((double)kp[((size_t)i * V + v) * 2 + 1] + oy);
+        const float cx = rintf(x / dsr), cy = rintf(y / dsr);
+        const bool in = !(cx < 0.0f) && !(cx >= (float)(W - 1)) && !(cy < 0.0f) && !(cy >= (float)(H - 1)) && cx == cx && cy == cy;
+        if (in) sum += vis[(size_t)i * V + v] * table[table_offset(vg_n, v, (int)cy * W + (int)cx)];
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+extern "C" int nemo_keypoint_corr(nemo_mesh_t m, const float* table, const float* kp_coords, const float* kp_vis,
+                                  const double* px_samples, const double* py_samples, int32_t n_pose, int32_t n_px,
+                                  int32_t n_py, float down_sample_rate, int32_t H, int32_t W, float* out, void* stream) {
+    if (n_pose == 0 || n_px == 0 || n_py == 0) return NEMO_OK;
+    if (!m || !table || !kp_coords || !kp_vis || !px_samples || !py_samples || !out || n_pose < 0 || n_px < 0 || n_py < 0 ||
+        H <= 1 || W <= 1 || !(down_sample_rate > 0.0f))
+        return fail(NEMO_ERR_INVALID, "nemo_keypoint_corr: bad argument");
+    const long long nwg = (long long)n_pose * n_px * n_py;
+    if (nwg > 0x7FFFFFFFLL) return fail(NEMO_ERR_UNSUPPORTED, "nemo_keypoint_corr: too many samples for one launch");
+    hipLaunchKernelGGL(keypoint_corr_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, table, kp_coords, kp_vis,
+                       px_samples, py_samples, m->V, n_px, n_py, down_sample_rate, H, W, out);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

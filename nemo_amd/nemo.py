@@ -13,6 +13,7 @@ import torch
 
 from . import ops
 from .batch_solve_pose import get_pre_render_samples, solve_pose as batch_solve_pose
+from .solve_pose import pre_compute_kp_coords, solve_pose as keypoint_solve_pose
 from .cameras import MeshRasterizer, PerspectiveCameras, RasterizationSettings
 from .feature_banks import FeatureBankNeMo
 from .mesh_interpolate_module import MeshInterpolateModule
@@ -77,8 +78,13 @@ class NeMo:
                                                   post_process=None).to(self.device)
         az, el, th, di, px, py = get_param_samples(self.cfg)
         self.init_mode = self.cfg.inference.get("init_mode", "3d_batch")
+        self._similarity = None
         if "batch" not in self.init_mode:
-            raise NotImplementedError("only the batched init modes (3d_batch / 6d_batch) are implemented")
+            # keypoint initialisation (reference nemo.py:313-320): projected vertices of every grid pose
+            self.poses, self.kp_coords, self.kp_vis = pre_compute_kp_coords(
+                xvert.numpy() if self._mesh is not None else self.mesh_path, azimuth_samples=az, elevation_samples=el,
+                theta_samples=th, distance_samples=di, viewport=cam_cfg.get("focal_length", 3000))
+            return
         dof = int(self.init_mode.split("d_")[0])
         self.feature_pre_rendered, self.cam_pos_pre_rendered, self.theta_pre_rendered = get_pre_render_samples(
             self.inter_module, azum_samples=az, elev_samples=el, theta_samples=th, distance_samples=di, device=self.device)
@@ -89,7 +95,6 @@ class NeMo:
             self.samples_principal = torch.stack(
                 (torch.from_numpy(px).view(-1, 1).expand(-1, py.shape[0]) * map_shape[1],
                  torch.from_numpy(py).view(1, -1).expand(px.shape[0], -1) * map_shape[0])).view(2, -1).T.float().to(self.device)
-        self._similarity = None
 
     # reference nemo.py:327-360
     def fast_inference(self, sample):
@@ -114,6 +119,11 @@ class NeMo:
         with torch.no_grad():
             feature_map = self.net.forward_test(img)
         b = feature_map.shape[0]
+        if "batch" not in self.init_mode:
+            assert b == 1, "The batch size during validation should be 1"
+            preds = keypoint_solve_pose(self.cfg, feature_map, self.inter_module, self.kp_features, self.clutter_bank, self.poses,
+                                        self.kp_coords, self.kp_vis, debug=debug, device=self.device)
+            return self._score_predictions([preds], sample)
         dof = int(self.init_mode.split("d_")[0])
         if dof == 6:
             principal = self.samples_principal
@@ -129,13 +139,19 @@ class NeMo:
             distance_source=sample["distance"].to(self.device) if (dof == 3 and "distance" in sample) else ones,
             distance_target=self.record_distance * ones if dof == 3 else ones,
             pre_render=self.cfg.inference.get("pre_render", True), dof=dof)
+        return self._score_predictions(preds, sample)
+
+    @staticmethod
+    def _score_predictions(preds, sample):
         classification_result = {}
         for i, pred in enumerate(preds):
             if "azimuth" in sample and "elevation" in sample and "theta" in sample:
-                err = pose_error({k: sample[k][i] for k in ["azimuth", "elevation", "theta"]}, pred["final"][0])
+                # with several refined proposals the keypoint solver returns the best one as a dict (solve_pose.py:329-338)
+                best = pred["final"][0] if isinstance(pred["final"], list) else pred["final"]
+                err = pose_error({k: sample[k][i] for k in ["azimuth", "elevation", "theta"]}, best)
                 pred["pose_error"] = err
                 if "this_name" in sample:
-                    classification_result[sample["this_name"][i]] = (pred["final"][0]["score"], err)
+                    classification_result[sample["this_name"][i]] = (best["score"], err)
         return preds, classification_result
 
 

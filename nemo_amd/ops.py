@@ -187,6 +187,17 @@ def table_dense(table, V, HW):
     return table.permute(0, 2, 4, 1, 3).reshape(B, vg * four, npt * T)[:, :V, :HW].contiguous()
 
 
+def table_from_dense(mesh, dense):
+    """[B, V, HW] -> the table layout (the inverse of table_dense; padding entries zero)."""
+    B, V, HW = dense.shape
+    if V != mesh.V:
+        raise ValueError("dense score map does not match the mesh")
+    _, npt, vg, T, four = table_shape(mesh, B, HW)
+    full = torch.zeros(B, vg * four, npt * T, device=dense.device, dtype=torch.float32)
+    full[:, :V, :HW] = dense
+    return full.view(B, vg, four, npt, T).permute(0, 3, 1, 4, 2).contiguous()
+
+
 def similarity_table(mesh, feature_map, out=None):
     """feature_map [B,C,H,W] -> table [B, ceil(HW/128), ceil(V/4), 128, 4]
     (element (b,v,p) at [b, p // 128, v // 4, p % 128, v % 4]; padding entries are zero)."""
@@ -265,6 +276,56 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
         check(lib.nemo_solve(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(cp), ptr(th), ptr(pr),
                              ptr(boxes, torch.int32), n_hyp, n_img, gb, int(dof), C.byref(opt), ptr(out), ptr(hist),
                              stream_ptr()), "nemo_solve")
+    return out, hist
+
+
+def keypoint_corr(mesh, table, kp_coords, kp_vis, px_samples, py_samples, down_sample_rate, H, W):
+    """get_corr_pytorch on the table of ONE image.  kp_coords [N,V,2] f32, kp_vis [N,V] f32, px/py samples f64
+    -> corr [N, n_px, n_py] f32."""
+    lib = _lib.load()
+    if tuple(table.shape) != table_shape(mesh, 1, H * W) or not table.is_contiguous():
+        raise ValueError("keypoint_corr takes the similarity table of exactly one image")
+    dev = table.device
+    kp = f32c(kp_coords.to(dev))
+    vis = f32c(kp_vis.to(dev))
+    N = kp.shape[0]
+    if tuple(kp.shape) != (N, mesh.V, 2) or tuple(vis.shape) != (N, mesh.V):
+        raise ValueError("kp_coords must be [N,V,2] and kp_vis [N,V]")
+    px = torch.as_tensor(px_samples, dtype=torch.float64).to(dev).contiguous()
+    py = torch.as_tensor(py_samples, dtype=torch.float64).to(dev).contiguous()
+    out = torch.empty(N, px.numel(), py.numel(), device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nemo_keypoint_corr(mesh.h, ptr(table), ptr(kp), ptr(vis), ptr(px, torch.float64), ptr(py, torch.float64), N,
+                                     px.numel(), py.numel(), float(down_sample_rate), H, W, ptr(out), stream_ptr()),
+              "nemo_keypoint_corr")
+    return out
+
+
+def solve_flow(mesh, cam, table, clu, init_campos, init_theta, init_flow=None, hyp_to_image=None, global_batch=None,
+               optimize_translation=True, translation_scale=0.1, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8,
+               lr_gamma=1.0, lr_every=0, history=False):
+    """The keypoint-initialised solver's Adam loop (translation = 2-D flow warp of the rendered map).
+    -> (pose [n_hyp,8]: cx, cy, cz, theta, flow_x, flow_y, score, first loss; loss_hist or None)."""
+    lib = _lib.load()
+    cp, th, fl, n_hyp = _pose_args(init_campos, init_theta, init_flow)
+    n_img = table.shape[0]
+    if hyp_to_image is None and n_hyp != n_img:
+        raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
+    h2i = None if hyp_to_image is None else hyp_to_image.to(device=cp.device, dtype=torch.int32).contiguous()
+    if h2i is not None and h2i.numel() and (int(h2i.min()) < 0 or int(h2i.max()) >= n_img):
+        raise ValueError("hyp_to_image out of range")
+    clu2 = f32c(clu).reshape(n_img, -1)
+    if tuple(table.shape) != table_shape(mesh, n_img, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
+        raise ValueError("table / clutter shapes do not match the mesh and camera")
+    opt = NemoAdam(int(steps), int(lr_every), float(lr), float(betas[0]), float(betas[1]), float(eps), float(lr_gamma))
+    out = torch.empty(n_hyp, 8, device=cp.device)
+    hist = torch.empty(n_hyp, steps, device=cp.device) if history else None
+    cc = cam.c()
+    gb = int(global_batch if global_batch is not None else n_img)
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_solve_flow(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(cp), ptr(th), ptr(fl),
+                                  n_hyp, n_img, gb, int(bool(optimize_translation)), float(translation_scale), C.byref(opt),
+                                  ptr(out), ptr(hist), stream_ptr()), "nemo_solve_flow")
     return out, hist
 
 

@@ -34,6 +34,9 @@ Reference files followed (read as text):
   nemo/utils/features.py            normalize_features :4-5
   nemo/utils/pose.py, evaluate.py   cal_rotation_matrix :56-59, pose_error :8-36
   data/create_cuboid_mesh.py        meshelize :22-97
+  nemo/models/solve_pose.py         get_corr_pytorch :27-82, solve_pose :85-347, pre_compute_kp_coords :405-562
+                                    (skimage.feature.peak_local_max of scikit-image 0.19.3 is restated from
+                                    its published algorithm on scipy.ndimage: absent here, PARITY UNPINNED)
 """
 import math
 
@@ -576,6 +579,165 @@ def solve_pose(inter, feature_map, clutter_bank, cam_pos_pre_rendered, theta_pre
                                       distance=dist[i].item(), principal=pp, score=scores[i].item())]))
     return preds, dict(init_idx=idx, init_loss=init_loss, init_C=init_C, init_theta=init_theta, C=C, theta=theta,
                        scores=scores, clutter=clu, hist=hist)
+
+
+# --------------------------------------------------------------------------------------
+# keypoint-initialised solver (nemo/models/solve_pose.py)
+# --------------------------------------------------------------------------------------
+def pre_compute_kp_coords(xvert, azimuth_samples, elevation_samples, theta_samples, distance_samples, viewport=3000):
+    """solve_pose.py:405-562 in the reference's f64 numpy arithmetic; kp_vis is all ones there."""
+    poses = np.array([[a, e, t, d] for a in azimuth_samples for e in elevation_samples for t in theta_samples
+                      for d in distance_samples], dtype=np.float32)
+    kp_coords = np.zeros((len(poses), len(xvert), 2), dtype=np.float32)
+    for i, pose_ in enumerate(poses):
+        azim_, elev_, theta_, dist_ = pose_
+        C = np.zeros((3, 1))
+        C[0] = dist_ * math.cos(elev_) * math.sin(azim_)
+        C[1] = -dist_ * math.cos(elev_) * math.cos(azim_)
+        C[2] = dist_ * math.sin(elev_)
+        azimuth = -azim_
+        elevation = -(math.pi / 2 - elev_)
+        Rz = np.array([[math.cos(azimuth), -math.sin(azimuth), 0], [math.sin(azimuth), math.cos(azimuth), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(elevation), -math.sin(elevation)], [0, math.sin(elevation), math.cos(elevation)]])
+        R_rot = np.dot(Rx, Rz)
+        R = np.hstack((R_rot, np.dot(-R_rot, C)))
+        P = np.array([[viewport, 0, 0], [0, viewport, 0], [0, 0, -1]])
+        x3d_ = np.hstack((xvert, np.ones((len(xvert), 1)))).T
+        x3d_ = np.dot(R, x3d_)
+        x2d = np.dot(P, x3d_)
+        x2d[0, :] = x2d[0, :] / x2d[2, :]
+        x2d[1, :] = x2d[1, :] / x2d[2, :]
+        x2d = x2d[0:2, :]
+        R2d = np.array([[math.cos(theta_), -math.sin(theta_)], [math.sin(theta_), math.cos(theta_)]])
+        x2d = np.dot(R2d, x2d).T
+        x2d[:, 1] *= -1
+        kp_coords[i] = x2d
+    poses = poses.reshape(len(azimuth_samples), len(elevation_samples), len(theta_samples), len(distance_samples), 4)
+    return poses, kp_coords, np.ones(kp_coords.shape[:2], dtype=np.float32)
+
+
+def get_corr(px_samples, py_samples, kpt_score_map, kp_coords, kp_vis, down_sample_rate, hm_h, hm_w):
+    """solve_pose.py:27-82 without the chunking: corr [n_pose, n_px, n_py]."""
+    px_s, py_s = torch.from_numpy(np.asarray(px_samples)), torch.from_numpy(np.asarray(py_samples))
+    kpc = torch.from_numpy(np.asarray(kp_coords)).clone()
+    kpv = torch.from_numpy(np.asarray(kp_vis)).clone()
+    kps = torch.as_tensor(kpt_score_map)
+    xv, yv = torch.meshgrid(px_s, py_s, indexing="ij")
+    principal_samples = torch.stack([xv, yv], dim=2).reshape(-1, 1, 2).repeat(1, kpc.shape[1], 1)
+    kpc = kpc.unsqueeze(1).repeat(1, principal_samples.shape[0], 1, 1)
+    kpc += principal_samples
+    kpc = kpc.reshape(-1, kpc.shape[2], 2)
+    kpc = torch.round(kpc / down_sample_rate)
+    kpv = kpv.unsqueeze(1).repeat(1, principal_samples.shape[0], 1)
+    kpv = kpv.reshape(-1, kpv.shape[2])
+    kpv[kpc[:, :, 0] < 0] = 0
+    kpv[kpc[:, :, 0] >= hm_w - 1] = 0
+    kpv[kpc[:, :, 1] < 0] = 0
+    kpv[kpc[:, :, 1] >= hm_h - 1] = 0
+    kpc[:, :, 0] = torch.clamp(kpc[:, :, 0], min=0, max=hm_w - 1)
+    kpc[:, :, 1] = torch.clamp(kpc[:, :, 1], min=0, max=hm_h - 1)
+    kpc = (kpc[:, :, 1:2] * hm_w + kpc[:, :, 0:1]).long()
+    corr = torch.take_along_dim(kps.unsqueeze(0), kpc, dim=2)[:, :, 0]
+    corr = torch.sum(corr * kpv, dim=1)
+    return corr.reshape(-1, len(px_s), len(py_s)).numpy()
+
+
+def peak_local_max(image, min_distance=1):
+    """skimage.feature.peak_local_max(image, min_distance, exclude_border=False) of scikit-image 0.19.3,
+    restated on scipy.ndimage (default thresholds: strictly above the image minimum; footprint
+    (2*min_distance+1)^2, maximum filter with mode='nearest'; no peaks in a flat image; highest first;
+    ensure_spacing drops a peak closer than min_distance (Chebyshev, strict) to a higher kept peak)."""
+    from scipy import ndimage as ndi
+    image = np.asarray(image)
+    size = 2 * min_distance + 1
+    if image.size == 1:
+        mask = image > image.min()
+    else:
+        mask = image == ndi.maximum_filter(image, footprint=np.ones((size, size), dtype=bool), mode="nearest")
+        if np.all(mask):
+            mask[:] = False
+        mask &= image > image.min()
+    coord = np.nonzero(mask)
+    idx = np.argsort(-image[coord], kind="stable")
+    coord = np.transpose(coord)[idx]
+    kept = []
+    for c in coord:
+        if all(np.abs(c - k).max() >= min_distance for k in kept):
+            kept.append(c)
+    return np.array(kept, dtype=np.int64).reshape(-1, 2)
+
+
+def keypoint_proposals(corr, poses, px_samples, py_samples, search_translation, min_distance, pre_rendering_thr):
+    """solve_pose.py:161-207."""
+    corr2d = corr.reshape(-1, len(px_samples), len(py_samples))
+    corr2d_max = np.max(corr2d, axis=0)
+    extrema_2d = peak_local_max(corr2d_max, min_distance=min_distance) if search_translation else [[0, 0]]
+    larger_thr_ext_2d, max_e, max_v = [], None, 0
+    for e in extrema_2d:
+        if corr2d_max[e[0], e[1]] >= pre_rendering_thr:
+            larger_thr_ext_2d.append(e)
+        if corr2d_max[e[0], e[1]] > max_v:
+            max_v = corr2d_max[e[0], e[1]]
+            max_e = e
+    extrema = []
+    for e in (larger_thr_ext_2d if len(larger_thr_ext_2d) > 0 else [max_e]):
+        c = corr2d[:, e[0], e[1]].reshape(poses.shape[0], poses.shape[1], poses.shape[2], poses.shape[3])
+        e_azim, e_elev, e_the, e_dist = np.unravel_index(np.argmax(c, axis=None), c.shape)
+        p = poses[e_azim, e_elev, e_the, e_dist]
+        extrema.append(dict(azimuth=p[0], elevation=p[1], theta=p[2], distance=p[3], px=px_samples[e[0]], py=py_samples[e[1]]))
+    return extrema, corr2d_max
+
+
+def refine_proposal(inter, feature_map, clu, C0, theta0, flow0, optimize_translation=True, translation_scale=0.1,
+                    epochs=300, lr=0.05, betas=(0.4, 0.6), record=False):
+    """solve_pose.py:223-324 for one proposal: Adam on (C [1,3], theta, flow [2]); the scheduler is built but
+    never stepped there, so the learning rate is constant.  feature_map [1,C,H,W], clu [1,H,W]."""
+    H, W = feature_map.shape[2:]
+    C = torch.nn.Parameter(C0.clone().view(1, 3))
+    theta = torch.nn.Parameter(theta0.clone().view(()))
+    flow = torch.nn.Parameter(flow0.clone().view(2))
+    params = [C, theta] + ([flow] if optimize_translation else [])
+    optim = torch.optim.Adam(params, lr=lr, betas=betas)
+    hist = []
+    loss = None
+    for epo in range(epochs):
+        projected = inter(C, theta.view(1))[0]                                   # [C,H,W]
+        flow_map = flow.view(1, 2, 1, 1).repeat(1, 1, H, W)
+        projected = flow_warp(projected.unsqueeze(0), flow_map / translation_scale)[0]
+        object_score = torch.sum(projected * feature_map[0], dim=0)
+        loss = torch.ones(1) - (torch.mean(torch.max(object_score, clu[0])) - torch.mean(clu[0]))
+        if record:
+            hist.append(float(loss.detach()))
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+    return C.detach()[0], theta.detach(), flow.detach(), float(loss.detach()), hist
+
+
+def solve_pose_keypoint(inter, feature_map, kp_features, clutter_bank, poses, kp_coords, kp_vis, px_samples, py_samples,
+                        down_sample_rate=8, search_translation=True, optimize_translation=True, min_distance=1,
+                        pre_rendering_thr=80, translation_scale=0.1, epochs=300, lr=0.05, betas=(0.4, 0.6)):
+    """solve_pose.py:85-347 (debug outputs omitted).  Returns (final, refined list, extrema, corr)."""
+    _, c, hm_h, hm_w = feature_map.shape
+    clu = clutter_score(feature_map, clutter_bank)
+    kpt_score_map = torch.einsum("vc,chw->vhw", kp_features, feature_map[0]).reshape(kp_features.shape[0], -1)
+    corr = get_corr(px_samples, py_samples, kpt_score_map, kp_coords, kp_vis, down_sample_rate, hm_h, hm_w)
+    extrema, _ = keypoint_proposals(corr, poses, px_samples, py_samples, search_translation, min_distance, pre_rendering_thr)
+    refined = []
+    for e in extrema:
+        C0 = camera_position_from_spherical_angles(torch.tensor([float(e["distance"])]), torch.tensor([float(e["elevation"])]),
+                                                   torch.tensor([float(e["azimuth"])]))
+        flow0 = torch.tensor([-(e["px"] - hm_w * down_sample_rate / 2) / down_sample_rate * translation_scale,
+                              -(e["py"] - hm_h * down_sample_rate / 2) / down_sample_rate * translation_scale], dtype=torch.float32)
+        Cr, thr, fl, score, _ = refine_proposal(inter, feature_map, clu, C0, torch.tensor(float(e["theta"])), flow0,
+                                                optimize_translation, translation_scale, epochs, lr, betas)
+        d, el, az = camera_position_to_spherical_angle(Cr.view(1, 3))
+        px_pred, py_pred = -float(fl[0]) / translation_scale, -float(fl[1]) / translation_scale
+        refined.append(dict(azimuth=float(az), elevation=float(el), theta=float(thr), distance=float(d), px=px_pred, py=py_pred,
+                            principal=[px_pred * down_sample_rate + hm_w * down_sample_rate / 2,
+                                       py_pred * down_sample_rate + hm_h * down_sample_rate / 2], score=score))
+    final = refined if len(refined) == 1 else min(refined, key=lambda r: r["score"])
+    return final, refined, extrema, corr
 
 
 # --------------------------------------------------------------------------------------

@@ -467,6 +467,37 @@ def test_nemo_facade_evaluate_and_fast_inference(small):
     assert labels == ["car"] * B and scores.shape == (B, 1)
 
 
+def test_nemo_facade_keypoint_init_mode(small):
+    """init_mode without 'batch' (reference nemo.py:313-320, 394-410): keypoint correlation + flow refinement."""
+    import nemo_amd
+    from nemo_amd.utils import ConfigNode, default_pose3d_config
+    sc = small
+    cfg = default_pose3d_config()
+    cfg.inference.init_mode = "6d"
+    cfg.inference.azim_sample = ConfigNode(dict(min_pi=0.0, max_pi=2.0, num=16))
+    cfg.inference.elev_sample = ConfigNode(dict(min_pi=-0.03, max_pi=0.06, num=2))
+    cfg.inference.theta_sample = ConfigNode(dict(min_pi=-0.08, max_pi=0.08, num=3))
+    cfg.inference.search_translation = True
+    cfg.inference.optimize_translation = True
+    cfg.inference.num_px_samples = 5
+    cfg.inference.num_py_samples = 5
+    cfg.inference.min_distance = 1
+    cfg.inference.pre_rendering_thr = 1e9
+    cfg.inference.translation_scale = 0.1
+    cfg.inference.epochs = 60
+    clutter_rows = torch.nn.functional.normalize(torch.randn(64, sc.C, generator=torch.Generator().manual_seed(3)), dim=1)
+    model = nemo_amd.NeMo(cfg, "car", mode="test", checkpoint=dict(memory=torch.cat([sc.mem, clutter_rows])),
+                          mesh=(sc.verts, sc.faces), image_size=(sc.H * 8, sc.W * 8), device=str(sc.device),
+                          inference=ConfigNode({"cameras": {"focal_length": 375.0 / 2 * 8}}))
+    assert model.kp_coords.shape == (16 * 2 * 3, sc.verts.shape[0], 2)
+    m, gt = R.synthetic_feature_map(sc.ref, model.clutter_bank.cpu(), 52)
+    sample = dict(img=m[None], azimuth=torch.tensor([gt["azimuth"]]), elevation=torch.tensor([gt["elevation"]]),
+                  theta=torch.tensor([gt["theta"]]), this_name=["im0"])
+    preds, cls = model.evaluate(sample)
+    assert len(preds) == 1 and preds[0]["pose_error"] * 180 / math.pi < 3.0 and "im0" in cls
+    assert abs(preds[0]["final"][0]["principal"][0] - sc.W * 4) < 4.0 and abs(preds[0]["final"][0]["principal"][1] - sc.H * 4) < 4.0
+
+
 def test_back_to_back_launches_are_reproducible(small):
     """The whole pipeline enqueued repeatedly without host synchronisation gives bitwise identical results
     (guards against intra-kernel races that only show under different wave timing)."""
@@ -490,3 +521,111 @@ def test_back_to_back_launches_are_reproducible(small):
     first = 1 - (torch.max(torch.zeros_like(ref), ref).mean(dim=(1, 2)) - ref.mean(dim=(1, 2)))
     assert float((outs[0][:, 7].cpu() - first).abs().max()) < 0.2      # first-step loss is a sane loss value
     assert float(outs[0][:, 6:8].max()) <= 1.0 + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# keypoint-initialised solver (reference nemo/models/solve_pose.py)
+# ---------------------------------------------------------------------------------------------
+KP_DSR = 8
+
+
+def _kp_grid(sc):
+    """Projected keypoints of a small pose grid.  The reference's keypoint camera (solve_pose.py:482-528) and
+    the renderer's look-at camera agree on the mesh as it is handed to both (checked to 1e-5 pixel)."""
+    xv = sc.verts.astype(np.float64)
+    az = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+    el = np.array([-0.1, 0.2])
+    th = np.array([-0.25, 0.0, 0.25])
+    di = np.array([5.0])
+    focal_full = float(sc.cam.focal) * KP_DSR
+    return xv, (az, el, th, di), R.pre_compute_kp_coords(xv, az, el, th, di, viewport=focal_full), focal_full
+
+
+def test_keypoint_corr_matches_oracle(small):
+    from nemo_amd import ops
+    from nemo_amd.solve_pose import pre_compute_kp_coords
+    sc = small
+    xv, grids, (poses, kpc, kpv), focal_full = _kp_grid(sc)
+    poses2, kpc2, kpv2 = pre_compute_kp_coords(xv, *grids, viewport=focal_full)
+    assert np.array_equal(poses, poses2) and np.array_equal(kpv, kpv2)
+    assert float(np.abs(kpc - kpc2).max()) < 1e-3 * max(1.0, float(np.abs(kpc).max()) * 1e-3)
+    kpv = kpv.copy()
+    kpv[:, ::7] = 0.0                                    # exercise the visibility weights
+    fm, _ = sc.feature_maps(1, first_seed=31)
+    px = np.linspace(0, sc.W * KP_DSR, 6, endpoint=True)
+    py = np.linspace(0, sc.H * KP_DSR, 5, endpoint=True)
+    dense = torch.einsum("vc,chw->vhw", sc.mem, fm[0]).reshape(sc.mem.shape[0], -1)
+    ref = R.get_corr(px, py, dense.numpy(), kpc, kpv, KP_DSR, sc.H, sc.W)
+    tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
+    got = ops.keypoint_corr(sc.mod.mesh, tab, torch.from_numpy(kpc), torch.from_numpy(kpv), px, py, KP_DSR, sc.H, sc.W).cpu()
+    assert got.shape == ref.shape
+    assert float(np.abs(got.numpy() - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+    # the dense form of the product API gives the same numbers
+    from nemo_amd.solve_pose import get_corr_pytorch
+    got2 = get_corr_pytorch(px, py, dense.numpy(), kpc, kpv, KP_DSR, sc.H, sc.W, device=sc.device, mesh=sc.mod.mesh)
+    assert float(np.abs(got2 - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("optimize_translation", [True, False])
+def test_flow_solve_first_steps_track_oracle(small, optimize_translation):
+    """nemo_solve_flow against autograd through render + flow_warp + Adam (constant learning rate)."""
+    from nemo_amd import ops
+    sc = small
+    fm, gts = sc.feature_maps(1, first_seed=40)
+    clu = R.clutter_score(fm, sc.clutter)
+    C0, th0 = random_poses(3, seed=9, dist=(4.8, 5.2))
+    fl0 = torch.tensor([[0.13, -0.21], [-0.34, 0.08], [0.017, -0.023]])       # off the pixel grid: see the kernel's note on kinks
+    tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
+    pose, lh = ops.solve_flow(sc.mod.mesh, sc.mod.camera(), tab, clu.to(sc.device), C0.to(sc.device), th0.to(sc.device),
+                              fl0.to(sc.device), hyp_to_image=torch.zeros(3, dtype=torch.int32), global_batch=1,
+                              optimize_translation=optimize_translation, translation_scale=0.1, steps=6, history=True)
+    pose, lh = pose.cpu(), lh.cpu()
+    for i in range(3):
+        Cr, thr, flr, score, hist = R.refine_proposal(sc.ref, fm, clu, C0[i], th0[i], fl0[i], optimize_translation, 0.1,
+                                                      epochs=6, record=True)
+        assert rel_err(lh[i], torch.tensor(hist)) < REL, (i, lh[i], hist)
+        assert rel_err(pose[i, 0:3], Cr) < 2e-4 and abs(float(pose[i, 3] - thr)) < 1e-3
+        assert float((pose[i, 4:6] - flr).abs().max()) < 1e-3
+        assert abs(float(pose[i, 6]) - score) < 1e-4
+        if not optimize_translation:
+            assert torch.equal(pose[i, 4:6], fl0[i])
+
+
+def test_keypoint_solve_pose_drop_in(small):
+    """solve_pose (keypoint initialisation, translation search + flow optimisation) against the oracle.
+    The reference never steps the learning-rate scheduler on this path (solve_pose.py:252-280), so Adam keeps
+    hopping around the optimum with a constant 0.05 step: the pose after N steps is reproducible to about a
+    degree only (the oracle itself lands 0.25 degree apart on two x86 hosts).  Proposals must match exactly;
+    the refined angles are compared at 1.5 degrees, and both must sit within 2 degrees of the ground truth."""
+    from nemo_amd.solve_pose import solve_pose
+    from nemo_amd.utils import ConfigNode
+    sc = small
+    xv, grids, (poses, kpc, kpv), focal_full = _kp_grid(sc)
+    fm, gts = sc.feature_maps(1, first_seed=52)
+    epochs = 40
+    cfg = ConfigNode({"model": {"down_sample_rate": KP_DSR},
+                      "inference": {"search_translation": True, "optimize_translation": True, "num_px_samples": 5,
+                                    "num_py_samples": 5, "min_distance": 1, "pre_rendering_thr": 1e9, "translation_scale": 0.1,
+                                    "epochs": epochs, "loss": "nemo.models.solve_pose.loss_fg_bg", "inter_mode": "bilinear",
+                                    "blur_radius": 0.0,
+                                    "optimizer": {"class_name": "torch.optim.Adam", "lr": 0.05, "betas": (0.4, 0.6)},
+                                    "scheduler": {"class_name": "torch.optim.lr_scheduler.ExponentialLR", "gamma": 0.2}}})
+    px = np.linspace(0, sc.W * KP_DSR, 5, endpoint=True)        # includes the image centre
+    py = np.linspace(0, sc.H * KP_DSR, 5, endpoint=True)
+    final_ref, refined_ref, extrema_ref, corr_ref = R.solve_pose_keypoint(
+        sc.ref, fm, sc.mem, sc.clutter, poses, kpc, kpv, px, py, down_sample_rate=KP_DSR, search_translation=True,
+        optimize_translation=True, min_distance=1, pre_rendering_thr=1e9, translation_scale=0.1, epochs=epochs)
+    pred = solve_pose(cfg, fm.to(sc.device), sc.mod, sc.mem.to(sc.device), sc.clutter.to(sc.device), poses, kpc, kpv, debug=True,
+                      device=sc.device)
+    assert len(pred["pre_rendering_poses"]) == len(extrema_ref) == 1          # below the threshold: the single best maximum
+    for k in ("azimuth", "elevation", "theta", "distance", "px", "py"):
+        assert float(pred["pre_rendering_poses"][0][k]) == float(extrema_ref[0][k]), k
+    got, ref = pred["final"][0], final_ref[0]
+    for k in ("azimuth", "elevation", "theta"):
+        assert angle_diff_deg(got[k], ref[k]) < 1.5, (k, got, ref)
+        assert angle_diff_deg(got[k], gts[0][k]) < 2.0 and angle_diff_deg(ref[k], gts[0][k]) < 2.0, (k, got, ref, gts[0])
+    assert abs(got["distance"] - ref["distance"]) < 0.05
+    assert abs(got["principal"][0] - ref["principal"][0]) < 1.0 and abs(got["principal"][1] - ref["principal"][1]) < 1.0
+    assert abs(got["score"] - ref["score"]) < 2e-2          # the loss of the last hop, see the docstring
+    assert pred["object_idx_map"].shape == (sc.H, sc.W) and pred["seg_maps"].shape == (1, sc.H, sc.W)
+    assert {"pre_compute_time", "pre_rendering_time", "optimization_time"} <= set(pred)
