@@ -9,6 +9,7 @@ from .cameras import MeshRasterizer, PerspectiveCameras, RasterizationSettings
 from .feature_banks import FeatureBankNeMo
 from .mesh_interpolate_module import MeshInterpolateModule
 from .nemo import NeMo, classify_by_render_compare
+from . import solve_pose_keypoint
 
 __all__ = ["ops", "get_pre_render_samples", "solve_pose", "MeshRasterizer", "PerspectiveCameras",
-           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "NeMo", "classify_by_render_compare"]
+           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "NeMo", "classify_by_render_compare", "solve_pose_keypoint"]

@@ -13,7 +13,7 @@ import torch
 
 from . import ops
 from .batch_solve_pose import get_pre_render_samples, solve_pose as batch_solve_pose
-from .solve_pose import pre_compute_kp_coords, solve_pose as keypoint_solve_pose
+from .solve_pose_keypoint import pre_compute_kp_coords, solve_pose as keypoint_solve_pose
 from .cameras import MeshRasterizer, PerspectiveCameras, RasterizationSettings
 from .feature_banks import FeatureBankNeMo
 from .mesh_interpolate_module import MeshInterpolateModule

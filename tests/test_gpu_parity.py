@@ -543,7 +543,7 @@ def _kp_grid(sc):
 
 def test_keypoint_corr_matches_oracle(small):
     from nemo_amd import ops
-    from nemo_amd.solve_pose import pre_compute_kp_coords
+    from nemo_amd.solve_pose_keypoint import pre_compute_kp_coords
     sc = small
     xv, grids, (poses, kpc, kpv), focal_full = _kp_grid(sc)
     poses2, kpc2, kpv2 = pre_compute_kp_coords(xv, *grids, viewport=focal_full)
@@ -561,7 +561,7 @@ def test_keypoint_corr_matches_oracle(small):
     assert got.shape == ref.shape
     assert float(np.abs(got.numpy() - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max()))
     # the dense form of the product API gives the same numbers
-    from nemo_amd.solve_pose import get_corr_pytorch
+    from nemo_amd.solve_pose_keypoint import get_corr_pytorch
     got2 = get_corr_pytorch(px, py, dense.numpy(), kpc, kpv, KP_DSR, sc.H, sc.W, device=sc.device, mesh=sc.mod.mesh)
     assert float(np.abs(got2 - ref).max()) < 1e-4 * max(1.0, float(np.abs(ref).max()))
 
@@ -597,7 +597,7 @@ def test_keypoint_solve_pose_drop_in(small):
     hopping around the optimum with a constant 0.05 step: the pose after N steps is reproducible to about a
     degree only (the oracle itself lands 0.25 degree apart on two x86 hosts).  Proposals must match exactly;
     the refined angles are compared at 1.5 degrees, and both must sit within 2 degrees of the ground truth."""
-    from nemo_amd.solve_pose import solve_pose
+    from nemo_amd.solve_pose_keypoint import solve_pose
     from nemo_amd.utils import ConfigNode
     sc = small
     xv, grids, (poses, kpc, kpv), focal_full = _kp_grid(sc)

@@ -276,7 +276,7 @@ def test_two_process_gather_gloo(tmp_path):
 # keypoint-initialised solver: host logic of the product against the oracle's restatement
 # ---------------------------------------------------------------------------------------------
 def test_peak_local_max_matches_scipy_restatement():
-    from nemo_amd.solve_pose import peak_local_max
+    from nemo_amd.solve_pose_keypoint import peak_local_max
     rng = np.random.RandomState(3)
     for shape in ((6, 6), (5, 9), (1, 7), (12, 12)):
         for md in (1, 2, 3):
@@ -293,7 +293,7 @@ def test_peak_local_max_matches_scipy_restatement():
 
 
 def test_keypoint_projection_and_proposals_match_oracle():
-    from nemo_amd.solve_pose import _proposals, pre_compute_kp_coords
+    from nemo_amd.solve_pose_keypoint import _proposals, pre_compute_kp_coords
     from nemo_amd.utils import ConfigNode
     verts, _ = R.cuboid_mesh(number_vertices=120)
     az, el, th, di = np.linspace(0, 2 * np.pi, 5, endpoint=False), np.array([0.0, 0.4]), np.array([-0.2, 0.3]), np.array([4.0, 6.0])
