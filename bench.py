@@ -215,6 +215,15 @@ def main():
         n_hyp_steps = args.steps * B * world * EPOCHS
         solve_ms = kern_ms["solve"]
         achieved = G * B * EPOCHS * ALGO_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9
+        # HBM-side traffic of the same launch shape, from the committed rocprofv3 --pmc passes (bench.py cannot
+        # run the profiler on itself); None when the launch shape differs from the profiled one.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_solve_traffic_v2.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("hypotheses_per_launch") == G * B and tj.get("adam_steps") == EPOCHS:
+                traffic = (tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -229,7 +238,9 @@ def main():
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
             "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": G * B * EPOCHS * ALGO_BYTES_PER_HYP_STEP,
+                         "traffic_source": "profiles/r1_solve_traffic_v2.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
                          "note": "achieved = 300 steps x hypotheses per launch x 4.128 MB (one read of the image's feature map + clutter "
                                  "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
                                  "kernel reads a precomputed vertex x pixel similarity table instead (3 floats per covered pixel), "
