@@ -67,7 +67,7 @@ def synthetic_images(mod, clutter, B, first_seed, dev):
     return torch.nn.functional.normalize(maps, dim=1).contiguous(), dict(azimuth=az, elevation=el, theta=th)
 
 
-def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=8):
+def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=100):
     """The oracle (PyTorch-CPU restatement of the reference's PyTorch3D CPU path) on this host's cores,
     on a bounded sample of the same workload: grid scoring of one image + n_steps Adam steps at B=1."""
     from oracle import refsolver as R
