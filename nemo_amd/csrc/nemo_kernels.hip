@@ -726,6 +726,15 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         __syncthreads();
     }
     const float fHW = (float)HW;
+    // world vertices of this thread, resident in registers when the mesh is small enough
+    const bool verts_resident = V <= kVertsPerThread * (int)blockDim.x;
+    float wv[kVertsPerThread][3];
+#pragma unroll
+    for (int k = 0; k < kVertsPerThread; ++k) {
+        const int v = tid + k * blockDim.x;
+        const bool ok = verts_resident && v < V;
+        wv[k][0] = ok ? a.rc.verts[3 * v] : 0.0f; wv[k][1] = ok ? a.rc.verts[3 * v + 1] : 0.0f; wv[k][2] = ok ? a.rc.verts[3 * v + 2] : 0.0f;
+    }
 #ifdef NEMO_STAMPS
     long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_t = clock64();
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         if (tid == 0) pose_setup<false>(a.rc.cc, os->P, os->P[3], WARP ? a.def_px : os->P[4], WARP ? a.def_py : os->P[5], s.pc);
         __syncthreads();
         STAMP(0);
-        project_vertices(a.rc, s);
+        if (verts_resident) project_vertices_resident(a.rc, s, wv); else project_vertices(a.rc, s);
         STAMP(1);
         raster_direct<FL>(a.rc, s);
 #ifdef NEMO_STAMPS_P1
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         }
         }
         STAMP(4);
-        block_sum<16>(vals, s.red, s.tot);
+        block_sum16(vals, s.red, s.tot);
         STAMP(5);
         if (WARP)       // the key buffer was not consumed by a compaction: empty the rows that were drawn
             for (int p = row0 * W + tid; p < row1 * W; p += blockDim.x) s.zbuf[p] = kEmptyKey;

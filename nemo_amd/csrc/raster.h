@@ -217,7 +217,81 @@ __device__ inline void project_vertices(const RasterCtx& rc, const Lds& s) {
     __syncthreads();
 }
 
+// Projection for the optimisation loop: the world vertices of a thread stay in registers over all steps
+// (wv[k] = vertex threadIdx.x + k * blockDim.x), reciprocal instead of division.  Ends with a barrier.
+constexpr int kVertsPerThread = 4;
+#pragma clang fp contract(fast)
+__device__ inline void project_vertices_resident(const RasterCtx& rc, const Lds& s, const float (*wv)[3]) {
+    float R[9], T[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = s.pc->R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = s.pc->T[i];
+    const float bx = s.pc->bx, by = s.pc->by, a = rc.cc.a;
+#pragma unroll
+    for (int k = 0; k < kVertsPerThread; ++k) {
+        const int v = threadIdx.x + k * blockDim.x;
+        if (v < rc.V) {
+            const float X = wv[k][0] * R[0] + wv[k][1] * R[3] + wv[k][2] * R[6] + T[0];
+            const float Y = wv[k][0] * R[1] + wv[k][1] * R[4] + wv[k][2] * R[7] + T[1];
+            const float Z = wv[k][0] * R[2] + wv[k][1] * R[5] + wv[k][2] * R[8] + T[2];
+            const float iz = __builtin_amdgcn_rcpf(Z);
+            s.verts[v] = make_float4(a * X * iz + bx, a * Y * iz + by, Z, iz);
+        }
+    }
+    __syncthreads();
+}
+#pragma clang fp contract(off)
+
 // Inclusive prefix sum of one int per lane over the wave (DPP within 16-lane rows, row totals via readlane).
+// Sixteen values per lane -> lane l of the wave returns the wave total of value (l & 15).  Butterfly over
+// the 16 lanes of a row in which every step halves the values a lane carries: at the step for index bit
+// b a lane keeps the half of its values whose bit b equals its own lane bit b and adds the same half
+// received from a partner that differs in lane bit b and agrees on the higher ones (row_mirror = xor 15,
+// row_half_mirror = xor 7, quad swaps = xor 2, xor 1).  15 DPP adds instead of 64, then two cross-row
+// shuffles.  The order of the additions is fixed, so the result is reproducible.
+template <int CTRL>
+__device__ inline float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float wave_sum16_transposed(const float* vals) {
+    const int lane = threadIdx.x & 63;
+    float a[8], b4[4], c2[2];
+    const bool h3 = lane & 8, h2 = lane & 4, h1 = lane & 2, h0 = lane & 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float keep = h3 ? vals[8 + j] : vals[j], send = h3 ? vals[j] : vals[8 + j];
+        a[j] = keep + dpp_get<0x140>(send);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = h2 ? a[4 + j] : a[j], send = h2 ? a[j] : a[4 + j];
+        b4[j] = keep + dpp_get<0x141>(send);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = h1 ? b4[2 + j] : b4[j], send = h1 ? b4[j] : b4[2 + j];
+        c2[j] = keep + dpp_get<0x4E>(send);
+    }
+    float r = (h0 ? c2[1] : c2[0]) + dpp_get<0xB1>(h0 ? c2[0] : c2[1]);
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    return r;
+}
+
+// Block total of exactly 16 values per thread (same contract as block_sum<16>).
+__device__ inline void block_sum16(const float* vals, float* red, float* tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float sv = wave_sum16_transposed(vals);
+    if (lane < 16) red[lane * 16 + wave] = sv;
+    __syncthreads();
+    if (threadIdx.x < 256) {          // one 16-lane row per value: lanes = the waves' partials (zero padded)
+        float t = row16_sum(red[threadIdx.x]);
+        if ((threadIdx.x & 15) == 0) tot[threadIdx.x >> 4] = t;
+    }
+    __syncthreads();
+}
+
 // Minimum / maximum of an int over the 64 lanes of a wave; every lane returns the result.
 template <int CTRL>
 __device__ inline int dpp_min(int v) { return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false)); }
