@@ -648,7 +648,7 @@ extern "C" int nemo_vertex_similarity(nemo_mesh_t m, const float* table, const f
 #endif
 
 struct OptState {
-    float P[6], m[6], v[6];
+    float P[6], m[6], v[6], g[6];
     double lr, b1p, b2p;
     float first_loss, last_loss;
     float base_max, base_clu, box_max, box_clu, box_n;   // per-image constants of the loss (see solve_kernel)
@@ -682,7 +682,15 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
     const float* clu = a.clu + (size_t)img * HW;
     raster_prologue(a.rc, s);
 
-    // optimiser state lives in LDS; only thread 0 touches it
+    // Adam's per-step constants (torch single-tensor path: bias corrections and step size in double, then
+    // cast): step_size = -lr_k / (1 - beta1^(k+1)), sqrt(1 - beta2^(k+1)); lr_k follows the exponential schedule.
+    float2* sched = (float2*)(smem + a.rc.L.sched);
+    for (int k = tid; k < min(a.steps, kSchedSteps); k += blockDim.x) {
+        const double lr_k = a.lr * (a.lr_every > 0 ? pow(a.gamma, (double)(k / a.lr_every)) : 1.0);
+        const double bc1 = 1.0 - pow(a.beta1, (double)(k + 1)), bc2 = 1.0 - pow(a.beta2, (double)(k + 1));
+        sched[k] = make_float2((float)(-(lr_k / bc1)), (float)sqrt(bc2));
+    }
+    // optimiser state lives in LDS; the first lanes of wave 0 touch it
     OptState* os = (OptState*)s.opt;
     const int np = a.dof == 6 ? 6 : 4;
     if (tid == 0) {
@@ -899,24 +907,33 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             float g[6];
             pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
             if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
-            // torch.optim.Adam (single-tensor path): lerp for the first moment, mul+addcmul for the
-            // second, bias corrections and step size in double, then addcdiv.
-            os->b1p *= a.beta1; os->b2p *= a.beta2;
-            const double bc1 = 1.0 - os->b1p, bc2 = 1.0 - os->b2p;
-            const float step_size = (float)(-(os->lr / bc1));
-            const float bc2s = (float)sqrt(bc2);
-            const float w1 = (float)(1.0 - a.beta1), b2f = (float)a.beta2, w2 = (float)(1.0 - a.beta2), epsf = (float)a.eps;
-            for (int k = 0; k < np; ++k) {
-                float gk = g[k];
-                float mk = os->m[k], vk = os->v[k];
-                float diff = gk - mk;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) os->g[k] = g[k];
+        }
+        // torch.optim.Adam (single-tensor path), one parameter per lane of wave 0: lerp for the first moment,
+        // mul + addcmul for the second, addcdiv.  LDS accesses of one wave complete in program order; the
+        // fence keeps the compiler from moving them.
+        if (tid < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (tid < np) {
+                float step_size, bc2s;
+                if (step < kSchedSteps) { const float2 sc = sched[step]; step_size = sc.x; bc2s = sc.y; }
+                else {
+                    const double lr_k = a.lr * (a.lr_every > 0 ? pow(a.gamma, (double)(step / a.lr_every)) : 1.0);
+                    step_size = (float)(-(lr_k / (1.0 - pow(a.beta1, (double)(step + 1)))));
+                    bc2s = (float)sqrt(1.0 - pow(a.beta2, (double)(step + 1)));
+                }
+                const float w1 = (float)(1.0 - a.beta1), b2f = (float)a.beta2, w2 = (float)(1.0 - a.beta2), epsf = (float)a.eps;
+                const float gk = os->g[tid];
+                float mk = os->m[tid], vk = os->v[tid];
+                const float diff = gk - mk;
                 mk = w1 < 0.5f ? mk + w1 * diff : gk - diff * (1.0f - w1);
                 vk = vk * b2f + (w2 * gk) * gk;
-                float denom = sqrtf(vk) / bc2s + epsf;
-                os->P[k] = os->P[k] + step_size * (mk / denom);
-                os->m[k] = mk; os->v[k] = vk;
+                const float denom = sqrtf(vk) / bc2s + epsf;
+                os->P[tid] = os->P[tid] + step_size * (mk / denom);
+                os->m[tid] = mk; os->v[tid] = vk;
             }
-            if (a.lr_every > 0 && (step + 1) % a.lr_every == 0) os->lr *= a.gamma;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         STAMP(6);
         // the next iteration's first barrier orders these LDS accesses before s.tot / s.pc are reused

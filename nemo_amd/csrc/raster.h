@@ -29,6 +29,7 @@ namespace nemo {
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kRasterThreads = 512;           // render kernels: 2 waves per SIMD, up to 256 registers each
 constexpr int kSolveThreads = 512;            // optimisation kernel (1024 threads would cap it at 128 registers: spills in the serial sections)
+constexpr int kSchedSteps = 512;              // optimiser steps whose Adam constants are tabulated in LDS
 constexpr int kMaxSide = 128;                // queue entry = xi | yi << 7 | face << 14
 constexpr int kPixBits = 14;
 constexpr int kMaxFaces = 1 << (32 - kPixBits);
@@ -53,6 +54,7 @@ struct LdsLayout {
     int tot;                    // f32 [16]
     int pc;                     // PoseCam
     int opt;                    // optimiser state (solve kernel) + queue counter
+    int sched;                  // float2 [kSchedSteps]: per-step Adam step size and sqrt of the second bias correction
     int total;
 };
 
@@ -77,6 +79,7 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
     L.tot = o; o = align16(o + 4 * 16);
     L.pc = o; o = align16(o + (int)sizeof(PoseCam));
     L.opt = o; o = align16(o + 256);
+    L.sched = o; o = align16(o + 8 * kSchedSteps);
     L.total = o;
     return L;
 }
