@@ -53,6 +53,7 @@ struct PoseCam {
     float nv, nw, nu;            // clamped norms of -C, up x z, z x x
     float sn, cs;                // sin, cos of theta
     int degenerate;
+    int cull;                    // optimisation loop: faces looking away from the camera may be skipped this step
 };
 
 __device__ inline void normalize3(float x, float y, float z, float* o, float* n_out) {

@@ -17,6 +17,10 @@
 #include <stdarg.h>
 #include <string.h>
 #include <new>
+#include <map>
+#include <array>
+#include <vector>
+#include <utility>
 
 #include "../../include/nemo_hip.h"
 #include "raster.h"
@@ -58,9 +62,83 @@ struct nemo_mesh_s {
     int32_t* faces;    // [F,3]
     float* memory;     // [V,C]
     float* memory_t;   // [C,V]
-    void* bank_frag;   // vertex bank as bf16-piece MFMA fragments (table_gemm.hip), or null when C does not qualify
+    void* bank_frag;   // vertex bank as f16-piece MFMA fragments (table_gemm.hip), or null when C does not qualify
+    int32_t* faces_outward;   // [F,3]: the faces wound counter-clockwise seen from outside, or null (see orient_faces)
+    float aabb[6];            // xmin, ymin, zmin, xmax, ymax, zmax of the vertices
     int device;
 };
+
+// Watertight-and-orientable test of a triangle mesh and outward re-winding of its faces (host, once per
+// mesh).  Vertices are welded by exact position first (the reference's cuboids duplicate the vertices
+// along the edges of their six sides, data/create_cuboid_mesh.py:22-97).  Succeeds only when every edge of
+// the welded mesh is shared by exactly two faces, the windings can be made consistent across every edge
+// and every connected component encloses a non-zero volume; then out[f] is face f with two indices
+// swapped where needed so that (v1-v0) x (v2-v0) points out of the solid.  The optimisation kernel uses
+// it to skip faces that look away from a camera outside the solid: such a face can never be the nearest
+// one at a pixel centre that a front face covers.
+static bool orient_faces(const std::vector<float>& v, const std::vector<int32_t>& f, int V, int F, std::vector<int32_t>* out) {
+    std::map<std::array<uint32_t, 3>, int> weld;
+    std::vector<int> canon(V);
+    for (int i = 0; i < V; ++i) {
+        std::array<uint32_t, 3> key;
+        for (int k = 0; k < 3; ++k) { float x = v[3 * i + k] + 0.0f; memcpy(&key[k], &x, 4); }       // +0.0f: -0 and +0 weld
+        canon[i] = weld.emplace(key, i).first->second;
+    }
+    struct Use { int face; bool forward; };
+    std::map<std::pair<int, int>, std::vector<Use>> edges;
+    for (int t = 0; t < F; ++t) {
+        int c[3];
+        for (int k = 0; k < 3; ++k) {
+            const int idx = f[3 * t + k];
+            if (idx < 0 || idx >= V) return false;
+            c[k] = canon[idx];
+        }
+        if (c[0] == c[1] || c[1] == c[2] || c[0] == c[2]) return false;
+        for (int k = 0; k < 3; ++k) {
+            const int a = c[k], b = c[(k + 1) % 3];
+            edges[{a < b ? a : b, a < b ? b : a}].push_back({t, a < b});
+        }
+    }
+    std::vector<std::vector<std::pair<int, bool>>> adj(F);      // neighbour, "same direction on the shared edge"
+    for (auto& e : edges) {
+        if (e.second.size() != 2) return false;
+        const Use &p = e.second[0], &q = e.second[1];
+        adj[p.face].push_back({q.face, p.forward == q.forward});
+        adj[q.face].push_back({p.face, p.forward == q.forward});
+    }
+    std::vector<int> flip(F, -1), comp(F, -1);
+    int ncomp = 0;
+    for (int s0 = 0; s0 < F; ++s0) {
+        if (flip[s0] >= 0) continue;
+        std::vector<int> stack{s0};
+        flip[s0] = 0; comp[s0] = ncomp;
+        while (!stack.empty()) {
+            const int t = stack.back(); stack.pop_back();
+            for (auto& nb : adj[t]) {
+                // consistent windings run along a shared edge in opposite directions
+                const int want = nb.second ? 1 - flip[t] : flip[t];
+                if (flip[nb.first] < 0) { flip[nb.first] = want; comp[nb.first] = ncomp; stack.push_back(nb.first); }
+                else if (flip[nb.first] != want) return false;
+            }
+        }
+        ++ncomp;
+    }
+    std::vector<double> vol(ncomp, 0.0), scale(ncomp, 0.0);
+    for (int t = 0; t < F; ++t) {
+        const int i0 = f[3 * t], i1 = f[3 * t + (flip[t] ? 2 : 1)], i2 = f[3 * t + (flip[t] ? 1 : 2)];
+        const double a[3] = {v[3 * i0], v[3 * i0 + 1], v[3 * i0 + 2]}, b[3] = {v[3 * i1], v[3 * i1 + 1], v[3 * i1 + 2]},
+                     c[3] = {v[3 * i2], v[3 * i2 + 1], v[3 * i2 + 2]};
+        const double d = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+        vol[comp[t]] += d;
+        scale[comp[t]] += d < 0 ? -d : d;
+    }
+    for (int k = 0; k < ncomp; ++k)
+        if (!(scale[k] > 0.0) || !((vol[k] < 0 ? -vol[k] : vol[k]) > 1e-9 * scale[k])) return false;
+    out->assign(f.begin(), f.end());
+    for (int t = 0; t < F; ++t)
+        if ((flip[t] != 0) != (vol[comp[t]] < 0)) std::swap((*out)[3 * t + 1], (*out)[3 * t + 2]);
+    return true;
+}
 
 // Layout of the similarity table: [image][pixel tile = ceil(HW / 128)][vertex group = ceil(V / 4)][128][4]:
 // element (v, p) of an image at ((p / 128 * VG + v / 4) * 128 + p % 128) * 4 + v % 4.  The producer's
@@ -101,12 +179,28 @@ extern "C" int nemo_mesh_create(const float* verts, const int32_t* faces, int32_
     if (!verts || !faces || !out || V <= 0 || F <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_create: bad argument");
     nemo_mesh_s* m = new (std::nothrow) nemo_mesh_s();
     if (!m) return fail(NEMO_ERR_INVALID, "out of host memory");
-    m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr; m->bank_frag = nullptr;
+    m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr; m->bank_frag = nullptr; m->faces_outward = nullptr;
     HIP_TRY(hipGetDevice(&m->device));
     HIP_TRY(hipMalloc((void**)&m->verts, sizeof(float) * 3 * V));
     HIP_TRY(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * F));
     HIP_TRY(hipMemcpy(m->verts, verts, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemcpy(m->faces, faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToDevice));
+    {
+        std::vector<float> hv((size_t)3 * V);
+        std::vector<int32_t> hf((size_t)3 * F), oriented;
+        HIP_TRY(hipMemcpy(hv.data(), verts, sizeof(float) * 3 * V, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hf.data(), faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; ++k) { m->aabb[k] = __builtin_inff(); m->aabb[3 + k] = -__builtin_inff(); }
+        for (int i = 0; i < V; ++i)
+            for (int k = 0; k < 3; ++k) {
+                m->aabb[k] = hv[3 * i + k] < m->aabb[k] ? hv[3 * i + k] : m->aabb[k];
+                m->aabb[3 + k] = hv[3 * i + k] > m->aabb[3 + k] ? hv[3 * i + k] : m->aabb[3 + k];
+            }
+        if (orient_faces(hv, hf, V, F, &oriented)) {
+            HIP_TRY(hipMalloc((void**)&m->faces_outward, sizeof(int32_t) * 3 * F));
+            HIP_TRY(hipMemcpy(m->faces_outward, oriented.data(), sizeof(int32_t) * 3 * F, hipMemcpyHostToDevice));
+        }
+    }
     *out = m;
     return NEMO_OK;
 }
@@ -138,6 +232,7 @@ extern "C" int nemo_mesh_destroy(nemo_mesh_t m) {
     if (m->memory) (void)hipFree(m->memory);
     if (m->memory_t) (void)hipFree(m->memory_t);
     if (m->bank_frag) (void)hipFree(m->bank_frag);
+    if (m->faces_outward) (void)hipFree(m->faces_outward);
     delete m;
     return NEMO_OK;
 }
@@ -284,6 +379,7 @@ extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* c
     if (out_maps && !m->memory_t) return fail(NEMO_ERR_STATE, "nemo_render: mesh has no vertex memory (call nemo_mesh_set_memory)");
     RenderArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.outward = 0;
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kRasterThreads, &a.rc.L);
     if (rcode) return rcode;
@@ -369,6 +465,7 @@ extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const
     if (!m->memory_t) return fail(NEMO_ERR_STATE, "nemo_render_backward: mesh has no vertex memory");
     RenderBwdArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.outward = 0;
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kRasterThreads, &a.rc.L);
     if (rcode) return rcode;
@@ -749,7 +846,17 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
 #endif
 
     for (int step = 0; step < a.steps; ++step) {
-        if (tid == 0) pose_setup<false>(a.rc.cc, os->P, os->P[3], WARP ? a.def_px : os->P[4], WARP ? a.def_py : os->P[5], s.pc);
+        if (tid == 0) {
+            pose_setup<false>(a.rc.cc, os->P, os->P[3], WARP ? a.def_px : os->P[4], WARP ? a.def_py : os->P[5], s.pc);
+            // back faces may be skipped while the camera is outside the solid (outside its bounding box, with a margin)
+            bool outside = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float m = 1e-3f * (a.rc.aabb[3 + k] - a.rc.aabb[k]) + 1e-6f;
+                outside = outside || os->P[k] < a.rc.aabb[k] - m || os->P[k] > a.rc.aabb[3 + k] + m;
+            }
+            s.pc->cull = a.rc.outward && outside;
+        }
         __syncthreads();
         STAMP(0);
         if (verts_resident) project_vertices_resident(a.rc, s, wv); else project_vertices(a.rc, s);
@@ -962,7 +1069,9 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve: negative step count");
     if (n_hyp == 0) return NEMO_OK;
     SolveArgs a;
-    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.outward = m->faces_outward != nullptr;
+    for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kSolveThreads, &a.rc.L);
     if (rcode) return rcode;
@@ -998,7 +1107,9 @@ extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const floa
     if (!(translation_scale > 0.0f)) return fail(NEMO_ERR_INVALID, "nemo_solve_flow: translation_scale must be positive");
     if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve_flow: negative step count");
     SolveArgs a;
-    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.outward = m->faces_outward != nullptr;
+    for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kSolveThreads, &a.rc.L);
     if (rcode) return rcode;

@@ -88,6 +88,8 @@ struct RasterCtx {
     const float* verts;
     const int32_t* faces;
     int V, F;
+    int outward;                // faces are wound counter-clockwise seen from outside a closed solid (optimisation loop only)
+    float aabb[6];              // bounding box of the vertices
     CamConst cc;
     LdsLayout L;
 };
@@ -514,7 +516,7 @@ struct WalkGrid { int H, W; float dx, dy, x_org, y_org, inv_dx, inv_dy; };
 
 // Straight-line: every quantity is computed for every lane and the pixel count n is zeroed for faces
 // that are skipped.  Returns true for a face that needs the exact rule (a vertex behind the camera).
-__device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, const FaceVerts& fv, WalkState* w, int* box) {
+__device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, bool cull, const FaceVerts& fv, WalkState* w, int* box) {
     const int H = g.H, W = g.W;
     const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2), zmin = fminf(fminf(fv.z0, fv.z1), fv.z2);
     // signed area = e0 evaluated at vertex 0
@@ -523,6 +525,9 @@ __device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, const Fa
     const float A2 = fv.y1 - fv.y0, B2 = fv.x0 - fv.x1;
     const float farea = A0 * (fv.x0 - fv.x1) + B0 * (fv.y0 - fv.y1);
     bool ok = valid && !(zmax < kEps) && (fabsf(farea) > kEps);            // false for NaN
+    // An outward-wound face seen from outside the solid looks at the camera when its signed area is positive.
+    ok = ok && (!cull || farea > 0.0f);
+    const float sgn = farea < 0.0f ? -1.0f : 1.0f;                          // edge functions oriented: inside means all positive
     const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
     const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
     const float tx0 = (xmin - g.x_org) * g.inv_dx - 1e-3f, tx1 = (xmax - g.x_org) * g.inv_dx + 1e-3f;
@@ -542,27 +547,28 @@ __device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, const Fa
     w->p = (H - 1 - jy0) * W + (W - 1 - jx0);          // pixel of the box origin; flipped indices grow downwards in p
     const float xo = (float)jx0 * g.dx + g.x_org, yo = (float)jy0 * g.dy + g.y_org;
     // e_i(x, y) = (x - xa)(yb - ya) - (y - ya)(xb - xa): value at the origin, step per column, step per row
-    w->e0 = (xo - fv.x1) * A0 + (yo - fv.y1) * B0;
-    w->e1 = (xo - fv.x2) * A1 + (yo - fv.y2) * B1;
-    w->e2 = (xo - fv.x0) * A2 + (yo - fv.y0) * B2;
-    w->a0 = A0 * g.dx; w->a1 = A1 * g.dx; w->a2 = A2 * g.dx;
+    w->e0 = sgn * ((xo - fv.x1) * A0 + (yo - fv.y1) * B0);
+    w->e1 = sgn * ((xo - fv.x2) * A1 + (yo - fv.y2) * B1);
+    w->e2 = sgn * ((xo - fv.x0) * A2 + (yo - fv.y0) * B2);
+    const float sdx = sgn * g.dx, sdy = sgn * g.dy;
+    w->a0 = A0 * sdx; w->a1 = A1 * sdx; w->a2 = A2 * sdx;
     // a row step also rewinds the nx columns walked
     const float back = (float)bx;
-    w->r0 = B0 * g.dy - back * w->a0; w->r1 = B1 * g.dy - back * w->a1; w->r2 = B2 * g.dy - back * w->a2;
+    w->r0 = B0 * sdy - back * w->a0; w->r1 = B1 * sdy - back * w->a1; w->r2 = B2 * sdy - back * w->a2;
     // u_i = e_i z_j z_k; corrected barycentrics u_i / sum(u); depth z0 z1 z2 (e0 + e1 + e2) / sum(u)
     const float z12 = fv.z1 * fv.z2, z02 = fv.z0 * fv.z2, z01 = fv.z0 * fv.z1;
     w->su = w->e0 * z12 + w->e1 * z02 + w->e2 * z01;
     w->asu = w->a0 * z12 + w->a1 * z02 + w->a2 * z01;
     w->rsu = w->r0 * z12 + w->r1 * z02 + w->r2 * z01;
-    w->numer = (fv.z0 * z12) * farea;
+    w->numer = (fv.z0 * z12) * fabsf(farea);
     return slow;
 }
 
 // One pixel centre of the walk: test, depth, key, then step to the next centre (k = index of this centre).
 __device__ inline void walk_step(WalkState& w, int k, unsigned long long* zbuf) {
-    const float lo = fminf(fminf(w.e0, w.e1), w.e2), hi = fmaxf(fmaxf(w.e0, w.e1), w.e2);
-    const float pz = w.numer * __builtin_amdgcn_rcpf(w.su);
-    if ((lo > 0.0f || hi < 0.0f) && pz >= 0.0f && k < w.n) atomicMin(&zbuf[w.p], depth_key(pz, w.face));
+    const float lo = fminf(fminf(w.e0, w.e1), w.e2);
+    const float pz = w.numer * __builtin_amdgcn_rcpf(w.su);          // positive: every term of su has the sign of its e_i
+    if (lo > 0.0f && k < w.n) atomicMin(&zbuf[w.p], depth_key(pz, w.face));
     ++w.c;
     const bool wrap = w.c == w.nx;
     const float wf = wrap ? 1.0f : 0.0f;
@@ -589,6 +595,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
 #endif
     const int lane = threadIdx.x & 63;
     const int ntask = (rc.F + 63) >> 6;
+    const bool cull = s.pc->cull != 0;          // set with the pose: outward faces and the camera outside the solid
     int row_lo = g.H, row_hi = -1;              // pixel rows (yi) this thread's faces may touch
     int task = threadIdx.x >> 6;
     // the vertex records of the next task are requested before the pixel walk of the current one
@@ -613,7 +620,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
         }
         WalkState w;
         int box[4];
-        const bool slow = walk_setup(g, f, f < rc.F, fv, &w, box);
+        const bool slow = walk_setup(g, f, f < rc.F, cull, fv, &w, box);
         if (w.n > 0 || slow) { row_lo = min(row_lo, g.H - 1 - box[3]); row_hi = max(row_hi, g.H - 1 - box[1]); }
         if (__any(slow)) {                       // rare: a face crossing the camera plane
             if (slow)

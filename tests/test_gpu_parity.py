@@ -630,3 +630,32 @@ def test_keypoint_solve_pose_drop_in(small):
     assert abs(got["score"] - ref["score"]) < 2e-2          # the loss of the last hop, see the docstring
     assert pred["object_idx_map"].shape == (sc.H, sc.W) and pred["seg_maps"].shape == (1, sc.H, sc.W)
     assert {"pre_compute_time", "pre_rendering_time", "optimization_time"} <= set(pred)
+
+
+@pytest.mark.parametrize("variant", ["mixed_winding", "open"])
+def test_solve_on_rewound_and_open_meshes(gpu, variant):
+    """The optimisation loop skips faces that look away from the camera only when the mesh is a closed,
+    orientable solid (faces are re-wound outward inside the handle); a mesh with arbitrary windings must give
+    the same trajectory as the oracle, and an open mesh (no skipping possible) as well."""
+    import nemo_amd
+    from nemo_amd import ops
+    base = Scene(40, 50, 32, 150, 375.0 / 2)
+    verts, faces = base.verts, base.faces.copy()
+    if variant == "mixed_winding":
+        faces[::2] = faces[::2][:, [0, 2, 1]]
+    else:
+        faces = faces[: (2 * faces.shape[0]) // 3]                      # drop a third of the faces: holes in the solid
+    ref = R.MeshInterpolateModuleRef(verts, faces, base.mem, base.cam)
+    cams = nemo_amd.PerspectiveCameras(focal_length=375.0 / 2, principal_point=((25, 20),), image_size=((40, 50),), in_ndc=False)
+    rs = nemo_amd.RasterizationSettings(image_size=(40, 50), blur_radius=0.0, faces_per_pixel=1, bin_size=0)
+    mod = nemo_amd.MeshInterpolateModule(torch.from_numpy(verts), torch.from_numpy(faces), base.mem,
+                                         rasterizer=nemo_amd.MeshRasterizer(cameras=cams, raster_settings=rs), post_process=None).to(gpu)
+    fm = torch.stack([R.synthetic_feature_map(ref, base.clutter, 70 + i)[0] for i in range(2)])
+    clu = R.clutter_score(fm, base.clutter)
+    C0, th0 = random_poses(2, seed=11, dist=(4.8, 5.2))
+    Cr, thr, _, scores, hist = R.optimize_poses(ref, fm, clu, C0, th0, epochs=5, record=True)
+    tab = ops.similarity_table(mod.mesh, fm.to(gpu))
+    pose, lh = ops.solve(mod.mesh, mod.camera(), tab, clu.to(gpu), C0.to(gpu), th0.to(gpu), steps=5, history=True)
+    per_image = torch.stack([h["per_image"] for h in hist], dim=1)
+    assert rel_err(lh.cpu(), per_image) < REL
+    assert rel_err(pose[:, 0:3].cpu(), Cr) < 2e-4
