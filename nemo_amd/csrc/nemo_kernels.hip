@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             // The covered entries of this wave, UNR per lane at a time, as straight-line code: the LDS
             // reads, the table / clutter gathers and the arithmetic of the UNR entries interleave.  A lane
             // whose batch runs past the end re-reads its first entry with weight 0.
-            constexpr int UNR = 3;
+            constexpr int UNR = 1;
             const float cam_a = a.rc.cc.a;
             for (int ib = tid & 63; ib < cnt; ib += 64 * UNR) {
                 int px[UNR], py[UNR], vi[UNR][3];
