@@ -125,6 +125,7 @@ def main():
     az, el, th, di, _, _ = get_param_samples(cfg)
     maps, cs, ths = nemo_amd.get_pre_render_samples(mod, az, el, th, di)     # one-off, untimed (like the reference's init)
     pre = maps.squeeze(1).contiguous()
+    packed = getattr(maps, "_nemo_packed_grid", None) or ops.grid_pack(pre)   # one-off, like the grid itself
     B = args.batch
     fm, gts = synthetic_images(mod, clutter, B, first_seed=rank * B, dev=dev)
     cam = mod.camera()
@@ -147,7 +148,7 @@ def main():
         clu = ops.clutter_score(x, clutter)
         if timed:
             ev[1].record()
-        _, idx, _ = ops.grid_score(pre, x, clu)
+        _, idx, _ = ops.grid_score(pre, x, clu, packed=packed)
         idx = idx.long()
         if timed:
             ev[2].record()

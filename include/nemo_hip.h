@@ -130,6 +130,20 @@ int nemo_grid_score(const float* pre, const float* feat, const float* clu, int32
                     int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same scoring on the matrix cores (v_mfma_f32_32x32x16_f16 on two-piece f16 operands: f32-grade
+ * accuracy).  The pre-rendered grid is packed once, next to its rendering (batch_solve_pose.py:43-62),
+ * into pixel-major fragment order; every call then converts the batch's feature maps to the same
+ * order inside the workspace and runs one [N x C].[C x B] product per pixel.  C must be 16, 32, 64 or
+ * 128 (nemo_grid_pack_bytes returns 0 otherwise: use nemo_grid_score).
+ * packed: device buffer of nemo_grid_pack_bytes(N, C, HW) bytes, filled by nemo_grid_pack.
+ * Outputs as nemo_grid_score; workspace of nemo_grid_score_packed_workspace(N, B, C, HW) bytes. */
+size_t nemo_grid_pack_bytes(int32_t N, int32_t C, int32_t HW);
+int nemo_grid_pack(const float* pre, int32_t N, int32_t C, int32_t HW, void* packed, void* stream);
+size_t nemo_grid_score_packed_workspace(int32_t N, int32_t B, int32_t C, int32_t HW);
+int nemo_grid_score_packed(const void* packed, const float* feat, const float* clu, int32_t N, int32_t B,
+                           int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- vertex x pixel similarity table --------------------------------------------------------
  * table[b,v,p] = sum_c memory[v,c] * feat[b,c,p]: the reference's kpt_score_map
  * (nemo/models/solve_pose.py:120-124) and the matmul of NeMo.fast_inference

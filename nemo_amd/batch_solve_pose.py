@@ -39,7 +39,10 @@ def get_pre_render_samples(inter_module, azum_samples, elev_samples, theta_sampl
     theta = torch.as_tensor(th, dtype=torch.float32).to(dev)
     with torch.no_grad():
         maps = inter_module(campos, theta)
-    return maps.unsqueeze(1), campos, theta
+    maps = maps.unsqueeze(1)
+    # the same grid in the matrix-core scoring layout (None for channel counts that form does not take)
+    maps._nemo_packed_grid = ops.grid_pack(maps.squeeze(1))
+    return maps, campos, theta
 
 
 def get_init_pos_rendered_dim0(samples_maps, samples_pos, samples_theta, predicted_maps, clutter_scores=None,
@@ -47,7 +50,7 @@ def get_init_pos_rendered_dim0(samples_maps, samples_pos, samples_theta, predict
     """(init campos [b,3], init theta [b], min loss [b]) - arg-min of the grid loss per image.
     `batch_size` (the reference's chunk size) is accepted and ignored: nothing is chunked."""
     pre = samples_maps.squeeze(1) if samples_maps.dim() == 5 else samples_maps
-    _, idx, mn = ops.grid_score(pre, predicted_maps, clutter_scores)
+    _, idx, mn = ops.grid_score(pre, predicted_maps, clutter_scores, packed=getattr(samples_maps, "_nemo_packed_grid", None))
     idx = idx.long()
     return samples_pos[idx], samples_theta[idx], mn
 

@@ -701,6 +701,61 @@ extern "C" int nemo_grid_score(const float* pre, const float* feat, const float*
     return NEMO_OK;
 }
 
+// ---- matrix-core form (kernels in grid_mfma.hip) ----
+namespace nemo {
+bool grid_mfma_supported(int C);
+int grid_chunks(int HW);
+size_t grid_pack_bytes(int N, int C, int HW);
+size_t grid_feat_bytes(int B, int C, int HW);
+int launch_grid_pack(const float* pre, void* packed, int N, int C, int HW, hipStream_t st);
+int launch_grid_mfma(const void* packed, const float* feat, const float* clu, int N, int B, int C, int HW, void* featp,
+                     float* partial, hipStream_t st);
+}
+
+extern "C" size_t nemo_grid_pack_bytes(int32_t N, int32_t C, int32_t HW) {
+    if (N <= 0 || C <= 0 || HW <= 0 || !nemo::grid_mfma_supported(C)) return 0;
+    return nemo::grid_pack_bytes(N, C, HW);
+}
+
+extern "C" int nemo_grid_pack(const float* pre, int32_t N, int32_t C, int32_t HW, void* packed, void* stream) {
+    if (!pre || !packed || N <= 0 || C <= 0 || HW <= 0) return fail(NEMO_ERR_INVALID, "nemo_grid_pack: bad argument");
+    if (!nemo::grid_mfma_supported(C))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_pack: %d channels (the matrix-core form takes 16, 32, 64 or 128)", C);
+    if (nemo::launch_grid_pack(pre, packed, N, C, HW, (hipStream_t)stream))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_pack: grid too large for one launch");
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t nemo_grid_score_packed_workspace(int32_t N, int32_t B, int32_t C, int32_t HW) {
+    if (N <= 0 || B <= 0 || C <= 0 || HW <= 0 || !nemo::grid_mfma_supported(C)) return 0;
+    return align256(nemo::grid_feat_bytes(B, C, HW)) + (size_t)nemo::grid_chunks(HW) * B * N * sizeof(float);
+}
+
+extern "C" int nemo_grid_score_packed(const void* packed, const float* feat, const float* clu, int32_t N, int32_t B, int32_t C,
+                                      int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!packed || !feat || !out_argmin || N <= 0 || B < 0 || C <= 0 || HW <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_packed: bad argument");
+    if (!nemo::grid_mfma_supported(C))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_packed: %d channels (takes 16, 32, 64 or 128)", C);
+    const size_t need = nemo_grid_score_packed_workspace(N, B, C, HW);
+    if (!workspace || workspace_bytes < need)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_packed: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)((char*)workspace + align256(nemo::grid_feat_bytes(B, C, HW)));
+    if (nemo::launch_grid_mfma(packed, feat, clu, N, B, C, HW, workspace, partial, st))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_packed: batch too large for one launch");
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)partial, clu, N, B, HW, nemo::grid_chunks(HW),
+                       out_loss, out_argmin, out_min);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // vertex similarity (fast_inference)
 // ------------------------------------------------------------------------------------------

@@ -28,7 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "split_f16.h"
+
 
 namespace nemo {
 
@@ -147,33 +148,8 @@ int launch_table_gemm(const float* memT, const float* feat, float* table, int V,
 // ---------------------------------------------------------------------------------------------
 // split-f16 path
 // ---------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));     // one MFMA operand fragment
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int SG_NP = 2;            // f16 pieces per f32 value
 constexpr int SG_PT = 128;          // pixels per workgroup
 constexpr int SG_THREADS = 256;     // 4 waves: 2 (vertex blocks of 64) x 2 (pixel blocks of 64)
-constexpr float SG_FEAT_SCALE = 256.0f;         // features are unit vectors per pixel: scaled values stay far inside f16
-constexpr float SG_FEAT_LIMIT = 65504.0f;       // largest finite f16: scaled features beyond it are clamped
-
-// x (already scaled) -> h = f16(x), l = f16(x - h), both round-to-nearest-even; x - h is exact in f32.
-// h + l carries 22 significant bits of x, and h*h' + h*l' + l*h' accumulated in f32 reproduces x*x' to
-// a few 1e-7 relative, the accuracy of an f32 multiply-add chain.
-__device__ inline void split2(float x0, float x1, uint32_t* h, uint32_t* l) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    union { f16x2 v; uint32_t u; } ph, pl;
-    ph.v = (f16x2){h0, h1}; pl.v = (f16x2){l0, l1};
-    *h = ph.u; *l = pl.u;
-}
-
-__device__ inline void split8(const float x[8], uint4 out[SG_NP]) {
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split2(x[2 * j], x[2 * j + 1], &h[j], &l[j]);
-    out[0] = make_uint4(h[0], h[1], h[2], h[3]);
-    out[1] = make_uint4(l[0], l[1], l[2], l[3]);
-}
 
 // Header of the bank fragment buffer (first 256 bytes): largest |memory| as float bits, the power-of-two
 // scale applied to the bank, and the factor that undoes both scales on the result.
@@ -214,10 +190,6 @@ __global__ void split_bank_kernel(const float* __restrict__ memory, BankMeta* me
     split8(x, pcs);
 #pragma unroll
     for (int pc = 0; pc < SG_NP; ++pc) frag[((size_t)(pc * nvb + vb) * nks + ks) * 64 + lane] = pcs[pc];
-}
-
-__device__ inline f16x8 as_frag(const uint4& u) {
-    union { uint4 u; f16x8 f; } c; c.u = u; return c.f;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

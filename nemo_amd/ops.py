@@ -150,14 +150,52 @@ def clutter_score(feature_map, clutter):
     return out
 
 
-def grid_score(pre_rendered, feature_map, clutter_score_map=None):
-    """pre_rendered [N,C,H,W], feature_map [B,C,H,W], clutter_score_map [B,H,W] or None
-    -> (loss [B,N], argmin [B] int32, min_loss [B])."""
+class PackedGrid:
+    """A pre-rendered pose grid in the matrix-core scoring layout (opaque device buffer + its shape)."""
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+
+def grid_pack(pre_rendered):
+    """pre_rendered [N,C,H,W] -> PackedGrid for grid_score(..., packed=...), or None when the channel count
+    is not one the matrix-core form takes (16, 32, 64, 128).  Do it once, next to the pre-rendering."""
     lib = _lib.load()
     pre = f32c(pre_rendered)
-    fm = f32c(feature_map)
     N, Cc, H, W = pre.shape
+    nbytes = lib.nemo_grid_pack_bytes(N, Cc, H * W)
+    if nbytes == 0:
+        return None
+    data = torch.empty(nbytes, dtype=torch.uint8, device=pre.device)
+    with torch.cuda.device(pre.device):
+        check(lib.nemo_grid_pack(ptr(pre), N, Cc, H * W, ptr(data, torch.uint8), stream_ptr()), "nemo_grid_pack")
+    return PackedGrid(data, pre.shape)
+
+
+def grid_score(pre_rendered, feature_map, clutter_score_map=None, packed=None):
+    """pre_rendered [N,C,H,W], feature_map [B,C,H,W], clutter_score_map [B,H,W] or None
+    -> (loss [B,N], argmin [B] int32, min_loss [B]).  With packed (grid_pack of the same grid) the scoring
+    runs on the matrix cores and pre_rendered is only consulted for its shape (it may be None)."""
+    lib = _lib.load()
+    fm = f32c(feature_map)
     B = fm.shape[0]
+    if packed is not None:
+        N, Cc, H, W = packed.shape
+        if tuple(fm.shape[1:]) != (Cc, H, W):
+            raise ValueError(f"feature_map {tuple(fm.shape)} does not match the packed grid {packed.shape}")
+        clu = None if clutter_score_map is None else f32c(clutter_score_map).reshape(B, H * W)
+        loss = torch.empty(B, N, device=fm.device)
+        amin = torch.empty(B, dtype=torch.int32, device=fm.device)
+        mn = torch.empty(B, device=fm.device)
+        nbytes = lib.nemo_grid_score_packed_workspace(N, B, Cc, H * W)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=fm.device)
+        with torch.cuda.device(fm.device):
+            check(lib.nemo_grid_score_packed(ptr(packed.data, torch.uint8), ptr(fm), ptr(clu), N, B, Cc, H * W, ptr(loss),
+                                             ptr(amin, torch.int32), ptr(mn), ptr(ws, torch.uint8), nbytes, stream_ptr()),
+                  "nemo_grid_score_packed")
+        return loss, amin, mn
+    pre = f32c(pre_rendered)
+    N, Cc, H, W = pre.shape
     if tuple(fm.shape[1:]) != (Cc, H, W):
         raise ValueError(f"feature_map {tuple(fm.shape)} does not match pre-rendered maps {tuple(pre.shape)}")
     clu = None if clutter_score_map is None else f32c(clutter_score_map).reshape(B, H * W)

@@ -144,8 +144,18 @@ def test_grid_score_small(small):
     assert rel_err(loss, loss_ref) < REL
     assert torch.equal(amin.cpu().long(), loss_ref.argmin(dim=1)), "grid arg-min differs"
     assert torch.allclose(mn.cpu(), loss_ref.min(dim=1)[0], rtol=REL, atol=0)
+    # the matrix-core form (two-piece f16 operands) against the same oracle numbers, same arg-min
+    packed = ops.grid_pack(maps.squeeze(1))
+    assert packed is not None
+    loss_p, amin_p, mn_p = ops.grid_score(None, fm.to(sc.device), clu.to(sc.device), packed=packed)
+    assert rel_err(loss_p, loss_ref) < REL
+    assert torch.equal(amin_p.cpu().long(), loss_ref.argmin(dim=1)), "grid arg-min differs (matrix-core form)"
+    assert torch.allclose(mn_p.cpu(), loss_ref.min(dim=1)[0], rtol=REL, atol=0)
+    assert float((loss_p - loss).abs().max()) < 2e-6
+    loss_p2, amin_p2, _ = ops.grid_score(None, fm.to(sc.device), None, packed=packed)
     # foreground-only variant (no clutter map)
     loss2, amin2, _ = ops.grid_score(maps.squeeze(1), fm.to(sc.device), None)
+    assert float((loss_p2 - loss2).abs().max()) < 2e-6 and torch.equal(amin_p2, amin2)
     obj = torch.einsum("nchw,bchw->bnhw", maps_ref.squeeze(1), fm)
     assert rel_err(loss2, 1 - obj.mean(dim=(2, 3))) < REL
 
