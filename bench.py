@@ -111,11 +111,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch through python -m torch.distributed.run --nproc-per-node N")
-    dev = torch.device(f"cuda:{local_rank}")
+    # NEMO_BENCH_REHEARSAL=1: several ranks share the visible GPUs and talk over gloo, to rehearse the N > 1
+    # code path on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("NEMO_BENCH_REHEARSAL") == "1"
+    dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count() if rehearsal else local_rank}")
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import nemo_amd
     from nemo_amd import ops
@@ -162,12 +168,17 @@ def main():
         sph = ops.spherical_angles(pose[:, 0:3])
         res = torch.cat([sph[:, 2:3], sph[:, 1:2], pose[:, 3:4], sph[:, 0:1], pose[:, 4:7]], dim=1)   # az, el, th, d, px, py, score
         if world > 1:
-            if g == G:
-                dist.all_gather(gathered, res.contiguous())
+            res = res.contiguous()
+            if rehearsal:                                     # gloo gathers host tensors
+                part = [torch.empty(n, 7) for _ in range(world)]
+                dist.all_gather(part, res.cpu())
+                res = torch.cat(part).to(dev)
+            elif g == G:
+                dist.all_gather(gathered, res)
                 res = torch.cat(gathered)
             else:
                 part = [torch.empty(n, 7, device=dev) for _ in range(world)]
-                dist.all_gather(part, res.contiguous())
+                dist.all_gather(part, res)
                 res = torch.cat(part)
         if host_out is not None:                    # the results go to (pinned) host memory per group
             host_out.copy_(res, non_blocking=True)
@@ -202,7 +213,7 @@ def main():
     elapsed = time.perf_counter() - t0
     res = host_res[0][:B]
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
