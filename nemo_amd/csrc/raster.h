@@ -1,8 +1,17 @@
 // Workgroup-level rasteriser front end shared by the solve / render / render-backward kernels.
-// One workgroup (16 waves) owns one camera pose; everything lives in LDS.  The kernels are bound by
-// vector-instruction issue, so the structure is about executing as few wave-instructions as possible:
+// One workgroup (8 waves) owns one camera pose; everything lives in LDS.  The kernels are bound by
+// vector-instruction issue, so the structure is about executing as few wave-instructions as possible.
 //
-//   project_vertices   every vertex -> NDC xy + view depth (one float4 record per vertex)
+// Common pieces:
+//   project_vertices   every vertex -> NDC xy, view depth and its reciprocal (one float4 record per vertex);
+//                      project_vertices_resident keeps the world vertices in registers over all steps
+//   compact_covered    each wave scans its own interleaved 64-pixel chunks of the key buffer (only the rows
+//                      the faces can touch), resets them for the next step and compacts the covered
+//                      (face, pixel) entries into its own segment: the pixel work that follows runs on
+//                      dense lanes, and because a wave only ever reads its own segment in a fixed order
+//                      every float sum is reproducible.
+//
+// Bit-exact rasteriser (render kernels: what a caller sees as an image):
 //   raster_pass1       one face per lane, registers only.  A conservative bounding box, then a cheap
 //                      conservative edge-sign test (fma arithmetic with an error margin) over its pixels;
 //                      survivors are recorded in a 64-bit mask.  The wave reserves queue space with one
@@ -12,13 +21,14 @@
 //   raster_pass2       the queue is consumed densely, one pair per lane: exact bounding-box test, exact
 //                      barycentrics and depth, 64-bit LDS atomic min on (depth bits << 32 | face).  The far
 //                      half runs after the near half and skips a pair whose face cannot beat the depth
-//                      already stored (its smallest vertex depth is larger): for a closed mesh that removes
-//                      almost all back-face evaluations.  Every decision that can change the winner uses
-//                      the exact arithmetic of geom.h, so the result equals a serial scan over the faces.
-//   compact_covered    each wave scans its own interleaved 64-pixel chunks of the key buffer, resets
-//                      them for the next step and compacts the covered (face, pixel) entries into its
-//                      own segment: the pixel work that follows runs on dense lanes, and because a wave
-//                      only ever reads its own segment in a fixed order every float sum is reproducible.
+//                      already stored.  Every decision that can change the winner uses the exact
+//                      arithmetic of geom.h, so the result equals a serial scan over the faces.
+//
+// Rasteriser of the optimisation loop (no image leaves the kernel):
+//   raster_direct      faces are handed out in tasks of 64 from an LDS counter; a lane orients its face's
+//                      edge functions, skips it when it looks away from a camera outside a closed solid,
+//                      and walks the pixel centres of its bounding box with incrementally stepped edge
+//                      functions and depth; same 64-bit atomic min.  No queue, no second pass.
 #pragma once
 #include "geom.h"
 

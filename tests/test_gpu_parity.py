@@ -669,3 +669,21 @@ def test_solve_on_rewound_and_open_meshes(gpu, variant):
     per_image = torch.stack([h["per_image"] for h in hist], dim=1)
     assert rel_err(lh.cpu(), per_image) < REL
     assert rel_err(pose[:, 0:3].cpu(), Cr) < 2e-4
+
+
+def test_grid_pack_falls_back_for_other_channel_counts(gpu):
+    """The matrix-core scoring takes 16/32/64/128 channels; any other count scores through the VALU kernel,
+    and solve_pose's helper picks whichever applies."""
+    import nemo_amd
+    from nemo_amd import ops
+    sc = Scene(24, 30, 24, 100, 375.0 / 4, device=gpu)
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az[:4], el[:2], th[:1], di)
+    assert ops.grid_pack(maps.squeeze(1)) is None and maps._nemo_packed_grid is None
+    fm, _ = sc.feature_maps(2)
+    clu = R.clutter_score(fm, sc.clutter)
+    maps_ref, _, _ = R.get_pre_render_samples(sc.ref, az[:4], el[:2], th[:1], di)
+    loss_ref = R.grid_losses(maps_ref, fm, clu).T
+    C0, th0, mn = nemo_amd.batch_solve_pose.get_init_pos_rendered_dim0(maps, cs, ths, fm.to(gpu), clu.to(gpu))
+    assert torch.equal(C0.cpu(), cs.cpu()[loss_ref.argmin(dim=1)])
+    assert torch.allclose(mn.cpu(), loss_ref.min(dim=1)[0], rtol=REL, atol=0)
