@@ -12,7 +12,8 @@
 //
 // A wave owns one column block (32 images) and walks the pixels of its chunk; for every pixel and row
 // block it runs 3 x C/16 v_mfma_f32_32x32x16_f16 and folds the 32 x 32 result tile into its running
-// sums with one max and one add per element.  The per-chunk sums go to the same partial buffer layout
+// sums with one max and one add per element.  The eight waves of a workgroup share the pose fragments
+// through LDS, so the packed grid is read once per 256 images.  The per-chunk sums go to the same partial buffer layout
 // as the VALU kernel's, so the deterministic finalize (sum over chunks, first-minimum arg-min) is shared.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -99,55 +100,88 @@ __global__ __launch_bounds__(256) void grid_feat_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // scoring
 // ---------------------------------------------------------------------------------------------
-template <int NKS>
-__global__ __launch_bounds__(256) void grid_mfma_kernel(const uint4* __restrict__ packed, const uint4* __restrict__ featp,
-                                                        const float* __restrict__ clu, int N, int B, int HW, int nrb, int ncb,
-                                                        float unscale, float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = blockIdx.x, cb = blockIdx.y * 4 + wave, rb0 = blockIdx.z * GM_RBG;
-    if (cb >= ncb) return;                               // no barriers in this kernel
-    const int nr = min(GM_RBG, nrb - rb0);
-    const int b = cb * 32 + (lane & 31), lk = lane >> 5;
-    const bool bvalid = b < B;
+// Workgroup = 8 waves = 8 column blocks (256 images) of one pixel chunk.  The pose fragments of a
+// (pixel, row block) stage - NKS * 2 KB, the same for every column block - are fetched once by the whole
+// workgroup and staged in LDS (double buffered); every wave multiplies them with its own image fragments,
+// which it holds in registers for the pixel.  The fetch of stage s+2 is issued before the MFMAs of stage
+// s, into one of two register sets, and written to LDS after the MFMAs of stage s+1.
+constexpr int GM_WAVES = 8;
+
+// NR = row blocks of this launch slice (compile time, so that the running sums, the LDS buffer and the
+// register set of every stage are addressed statically: the stage loop is unrolled over two pixels).
+template <int NKS, int NR>
+__global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* __restrict__ packed, const uint4* __restrict__ featp,
+                                                                 const float* __restrict__ clu, int N, int B, int HW, int nrb,
+                                                                 int ncb, int rb0, float unscale, float* __restrict__ partial) {
+    constexpr int STAGE_U4 = NKS * 2 * 64;                       // uint4 per stage
+    constexpr int PER_THREAD = (STAGE_U4 + 64 * GM_WAVES - 1) / (64 * GM_WAVES);
+    __shared__ uint4 abuf[2][STAGE_U4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, cb = blockIdx.y * GM_WAVES + wave;
+    const bool wave_on = cb < ncb;                               // idle waves still help with the staging
+    const int cbc = wave_on ? cb : ncb - 1;
+    const int b = cbc * 32 + (lane & 31), lk = lane >> 5;
+    const bool bvalid = wave_on && b < B;
     const int p_begin = chunk * GM_CHUNK, p_end = min(p_begin + GM_CHUNK, HW);
+    const int nstage = (p_end - p_begin) * NR;
 
-    f32x16 lacc[GM_RBG];
+    uint4 q[2][PER_THREAD];
+    auto fetch = [&](int st, uint4* dst) {
+        const uint4* src = packed + (((size_t)(p_begin + st / NR) * nrb + rb0 + st % NR) * NKS) * 2 * 64;
 #pragma unroll
-    for (int r = 0; r < GM_RBG; ++r) lacc[r] = (f32x16){0};
+        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) dst[i] = src[e]; }
+    };
+    auto park = [&](int buf, const uint4* src) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) abuf[buf][e] = src[i]; }
+    };
 
-    for (int p = p_begin; p < p_end; ++p) {
-        f16x8 bh[NKS], bl[NKS];
-        const uint4* bp = featp + (((size_t)p * ncb + cb) * NKS) * 2 * 64 + lane;
+    f32x16 lacc[NR];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) { bh[ks] = as_frag(bp[(ks * 2 + 0) * 64]); bl[ks] = as_frag(bp[(ks * 2 + 1) * 64]); }
-        const float cl = (clu && bvalid) ? clu[(size_t)b * HW + p] : -__builtin_inff();
+    for (int r = 0; r < NR; ++r) lacc[r] = (f32x16){0};
+    f16x8 bh[NKS], bl[NKS];
+    float cl = -__builtin_inff();
+
+    if (nstage > 0) { fetch(0, q[0]); park(0, q[0]); }
+    if (nstage > 1) fetch(1, q[1]);
+    __syncthreads();
+    for (int st0 = 0; st0 < nstage; st0 += 2 * NR) {
 #pragma unroll
-        for (int r = 0; r < GM_RBG; ++r) {
-            if (r < nr) {
-                const uint4* ap = packed + (((size_t)p * nrb + rb0 + r) * NKS) * 2 * 64 + lane;
-                f32x16 S = {0};
+        for (int u = 0; u < 2 * NR; ++u) {
+            const int st = st0 + u;
+            if (st >= nstage) break;
+            const int r = u % NR, buf = u & 1;                   // compile-time after unrolling (2 * NR is even)
+            // stage st is in LDS buffer `buf`; register set 1 - buf holds stage st + 1; set `buf` is free
+            if (st + 2 < nstage) fetch(st + 2, q[buf]);
+            if (r == 0) {                                        // new pixel: this wave's image fragments
+                const int p = p_begin + st / NR;
+                const uint4* bp = featp + (((size_t)p * ncb + cbc) * NKS) * 2 * 64 + lane;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const f16x8 ah = as_frag(ap[(ks * 2 + 0) * 64]), al = as_frag(ap[(ks * 2 + 1) * 64]);
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], S, 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) lacc[r][i] += fmaxf(S[i] * unscale, cl);      // cl = -inf without a clutter map
+                for (int ks = 0; ks < NKS; ++ks) { bh[ks] = as_frag(bp[(ks * 2 + 0) * 64]); bl[ks] = as_frag(bp[(ks * 2 + 1) * 64]); }
+                cl = (clu && bvalid) ? clu[(size_t)b * HW + p] : -__builtin_inff();
             }
+            f32x16 S = {0};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const f16x8 ah = as_frag(abuf[buf][(ks * 2 + 0) * 64 + lane]), al = as_frag(abuf[buf][(ks * 2 + 1) * 64 + lane]);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], S, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lacc[r][i] += fmaxf(S[i] * unscale, cl);          // cl = -inf without a clutter map
+            if (st + 1 < nstage) park(1 - buf, q[1 - buf]);
+            __syncthreads();
         }
     }
     if (!bvalid) return;
     float* out = partial + ((size_t)chunk * B + b) * N;
 #pragma unroll
-    for (int r = 0; r < GM_RBG; ++r) {
-        if (r < nr) {
+    for (int r = 0; r < NR; ++r) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = (rb0 + r) * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;      // C/D layout of the 32x32 tile
-                if (n < N) out[n] = lacc[r][i];
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int n = (rb0 + r) * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;          // C/D layout of the 32x32 tile
+            if (n < N) out[n] = lacc[r][i];
         }
     }
 }
@@ -166,20 +200,37 @@ int launch_grid_pack(const float* pre, void* packed, int N, int C, int HW, hipSt
     return 0;
 }
 
+template <int NKS, int NR>
+static void launch_mfma_slice(const void* packed, const void* featp, const float* clu, int N, int B, int HW, int rb0, float* partial,
+                              hipStream_t st) {
+    const int nrb = (N + 31) / 32, ncb = (B + 31) / 32;
+    dim3 grid(grid_chunks(HW), (ncb + GM_WAVES - 1) / GM_WAVES);
+    hipLaunchKernelGGL((grid_mfma_kernel<NKS, NR>), grid, dim3(64 * GM_WAVES), 0, st, (const uint4*)packed, (const uint4*)featp, clu, N,
+                       B, HW, nrb, ncb, rb0, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial);
+}
+
+// All row blocks of the grid, GM_RBG at a time (one launch per slice; 144 poses are one slice).
 template <int NKS>
 static void launch_mfma_nks(const void* packed, const void* featp, const float* clu, int N, int B, int HW, float* partial,
                             hipStream_t st) {
-    const int nrb = (N + 31) / 32, ncb = (B + 31) / 32;
-    dim3 grid(grid_chunks(HW), (ncb + 3) / 4, (nrb + GM_RBG - 1) / GM_RBG);
-    hipLaunchKernelGGL(grid_mfma_kernel<NKS>, grid, dim3(256), 0, st, (const uint4*)packed, (const uint4*)featp, clu, N, B, HW, nrb,
-                       ncb, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial);
+    const int nrb = (N + 31) / 32;
+    for (int rb0 = 0; rb0 < nrb; rb0 += GM_RBG) {
+        switch (nrb - rb0 < GM_RBG ? nrb - rb0 : GM_RBG) {
+            case 1: launch_mfma_slice<NKS, 1>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
+            case 2: launch_mfma_slice<NKS, 2>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
+            case 3: launch_mfma_slice<NKS, 3>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
+            case 4: launch_mfma_slice<NKS, 4>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
+            default: launch_mfma_slice<NKS, 5>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
+        }
+    }
 }
 
 // featp: grid_feat_bytes(B, C, HW) bytes of scratch; partial: grid_chunks(HW) * B * N floats.
 int launch_grid_mfma(const void* packed, const float* feat, const float* clu, int N, int B, int C, int HW, void* featp,
                      float* partial, hipStream_t st) {
     const int ncb = (B + 31) / 32, nrb = (N + 31) / 32;
-    if (ncb > 65535 || (ncb + 3) / 4 > 65535 || (nrb + GM_RBG - 1) / GM_RBG > 65535) return -1;
+    if (ncb > 65535) return -1;
+    (void)nrb;
     hipLaunchKernelGGL(grid_feat_kernel, dim3((HW + GF_PX - 1) / GF_PX, C / 16, ncb), dim3(256), 0, st, feat, (uint4*)featp, B, C, HW,
                        ncb);
     switch (C / 16) {
