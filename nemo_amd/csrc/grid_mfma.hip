@@ -125,15 +125,18 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
     const int p_begin = chunk * GM_CHUNK, p_end = min(p_begin + GM_CHUNK, HW);
     const int nstage = (p_end - p_begin) * NR;
 
-    uint4 q[2][PER_THREAD];
-    auto fetch = [&](int st, uint4* dst) {
+    struct Staged { uint4 v[PER_THREAD]; };                      // one thread's share of a stage, held in registers
+    Staged qa = {}, qb = {};                                     // register sets 0 and 1
+    auto fetch = [&](int st) {
         const uint4* src = packed + (((size_t)(p_begin + st / NR) * nrb + rb0 + st % NR) * NKS) * 2 * 64;
+        Staged q = {};
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) dst[i] = src[e]; }
+        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) q.v[i] = src[e]; }
+        return q;
     };
-    auto park = [&](int buf, const uint4* src) {
+    auto park = [&](int buf, const Staged& q) {
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) abuf[buf][e] = src[i]; }
+        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) abuf[buf][e] = q.v[i]; }
     };
 
     f32x16 lacc[NR];
@@ -142,17 +145,17 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
     f16x8 bh[NKS], bl[NKS];
     float cl = -__builtin_inff();
 
-    if (nstage > 0) { fetch(0, q[0]); park(0, q[0]); }
-    if (nstage > 1) fetch(1, q[1]);
+    if (nstage > 0) { qa = fetch(0); park(0, qa); }
+    if (nstage > 1) qb = fetch(1);
     __syncthreads();
     for (int st0 = 0; st0 < nstage; st0 += 2 * NR) {
 #pragma unroll
         for (int u = 0; u < 2 * NR; ++u) {
             const int st = st0 + u;
-            if (st >= nstage) break;
+            if (st >= nstage) continue;                          // workgroup-uniform (odd pixel count: the tail of the last pair)
             const int r = u % NR, buf = u & 1;                   // compile-time after unrolling (2 * NR is even)
             // stage st is in LDS buffer `buf`; register set 1 - buf holds stage st + 1; set `buf` is free
-            if (st + 2 < nstage) fetch(st + 2, q[buf]);
+            if (st + 2 < nstage) { if (buf == 0) qa = fetch(st + 2); else qb = fetch(st + 2); }
             if (r == 0) {                                        // new pixel: this wave's image fragments
                 const int p = p_begin + st / NR;
                 const uint4* bp = featp + (((size_t)p * ncb + cbc) * NKS) * 2 * 64 + lane;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) lacc[r][i] += fmaxf(S[i] * unscale, cl);          // cl = -inf without a clutter map
-            if (st + 1 < nstage) park(1 - buf, q[1 - buf]);
+            if (st + 1 < nstage) { if (buf == 0) park(1, qb); else park(0, qa); }
             __syncthreads();
         }
     }
