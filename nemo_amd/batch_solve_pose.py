@@ -155,16 +155,22 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
         assert pre_render
         principal = principal.float().to(dev)
         ones = torch.ones(b, device=dev)
+        # Every principal sample re-centres the whole batch (batch_solve_pose.py:264-295).  The re-centred
+        # copies are scored together, a few samples per grid-scoring launch, so the pre-rendered grid is
+        # streamed once per launch instead of once per sample; results per sample are unchanged.
         all_C, all_theta, all_loss = [], [], []
-        for principal_ in principal:
-            t_feature_map = align_no_centered(feature_map, ones, principal_, target_shape, ones, centre, padding_mode="border")
-            t_clutter_score = align_no_centered(clutter_score[:, None], ones, principal_, target_shape, ones, centre,
-                                                padding_mode="border").squeeze(1)
-            this_C, this_theta, this_loss = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
-                                                                       theta_pre_rendered, t_feature_map, t_clutter_score)
-            all_C.append(this_C)
-            all_theta.append(this_theta)
-            all_loss.append(this_loss)
+        per_call = max(1, 1024 // max(b, 1))
+        for s0 in range(0, principal.shape[0], per_call):
+            chunk = principal[s0:s0 + per_call]
+            fms = [align_no_centered(feature_map, ones, p_, target_shape, ones, centre, padding_mode="border") for p_ in chunk]
+            cls = [align_no_centered(clutter_score[:, None], ones, p_, target_shape, ones, centre, padding_mode="border").squeeze(1)
+                   for p_ in chunk]
+            C_, th_, loss_ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered,
+                                                        torch.cat(fms), torch.cat(cls))
+            for k in range(chunk.shape[0]):
+                all_C.append(C_[k * b:(k + 1) * b])
+                all_theta.append(th_[k * b:(k + 1) * b])
+                all_loss.append(loss_[k * b:(k + 1) * b])
         use = torch.min(torch.stack(all_loss), dim=0)[1]
         ar = torch.arange(b, device=dev)
         init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_theta)[use, ar]
