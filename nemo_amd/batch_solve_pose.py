@@ -46,11 +46,19 @@ def get_pre_render_samples(inter_module, azum_samples, elev_samples, theta_sampl
 
 
 def get_init_pos_rendered_dim0(samples_maps, samples_pos, samples_theta, predicted_maps, clutter_scores=None,
-                               batch_size=32):
+                               batch_size=32, top_k=1):
     """(init campos [b,3], init theta [b], min loss [b]) - arg-min of the grid loss per image.
-    `batch_size` (the reference's chunk size) is accepted and ignored: nothing is chunked."""
+    `batch_size` (the reference's chunk size) is accepted and ignored: nothing is chunked.
+    With top_k > 1 the k lowest-loss grid poses of every image come back instead, best first:
+    (campos [b,k,3], theta [b,k], loss [b,k]); column 0 is the arg-min pose."""
     pre = samples_maps.squeeze(1) if samples_maps.dim() == 5 else samples_maps
-    _, idx, mn = ops.grid_score(pre, predicted_maps, clutter_scores, packed=getattr(samples_maps, "_nemo_packed_grid", None))
+    loss, idx, mn = ops.grid_score(pre, predicted_maps, clutter_scores, packed=getattr(samples_maps, "_nemo_packed_grid", None))
+    if top_k > 1:
+        if top_k > loss.shape[1]:
+            raise ValueError(f"top_k={top_k} exceeds the {loss.shape[1]} poses of the grid")
+        # a stable ascending sort keeps the first minimum in column 0, as the device arg-min does
+        order = torch.sort(loss, dim=1, stable=True)[1][:, :top_k]
+        return samples_pos[order], samples_theta[order], torch.gather(loss, 1, order)
     idx = idx.long()
     return samples_pos[idx], samples_theta[idx], mn
 
@@ -107,8 +115,12 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     """Same contract as the reference (batch_solve_pose.py:194-372): a list (one entry per image) of
     dict(final=[dict(azimuth, elevation, theta, distance, principal=[px,py], score)],
          pre_compute_time, pre_rendering_time, optimization_time).
-    kwargs: distance_source, distance_target (re-centring), down_sample_rate (bbox), and the extra
-    `global_batch`: size of the batch the images are a shard of (defaults to b)."""
+    kwargs: distance_source, distance_target (re-centring), down_sample_rate (bbox), and two extras:
+    `global_batch`: size of the batch the images are a shard of (defaults to b);
+    `hypotheses`: K >= 1 initial poses per image (default 1, the reference's behaviour).  With K > 1 the K
+    lowest-loss grid poses of every image (dof 3/4) or the best pose of each of the K best principal samples
+    (dof 6) are all optimised by the same launch, every one exactly as a K = 1 run started there would be,
+    and `final` lists the K refined poses best score first (`final[0]` is the answer)."""
     b, c, hm_h, hm_w = feature_map.shape
     if dof not in (3, 4, 6):
         raise ValueError("dof must be 3, 4 or 6")
@@ -118,6 +130,11 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     epochs = int(cfg.inference.epochs)
     dev = feature_map.device
     pred = {}
+    n_hyp = int(kwargs.get("hypotheses", 1))
+    if n_hyp < 1:
+        raise ValueError("hypotheses must be >= 1")
+    if n_hyp > 1 and dof != 6 and not pre_render:
+        raise NotImplementedError("hypotheses > 1 needs the pre-rendered grid")
 
     # Step 1: clutter score
     t0 = time.time()
@@ -146,7 +163,12 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
             t_feature_map, t_clutter_score = feature_map, clutter_score
         if pre_render:
             init_C, init_theta, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
-                                                               theta_pre_rendered, t_feature_map, t_clutter_score)
+                                                               theta_pre_rendered, t_feature_map, t_clutter_score,
+                                                               top_k=n_hyp)
+            if n_hyp > 1:                        # [b, K, ...] -> hypothesis-major rows i * K + k
+                init_C, init_theta = init_C.reshape(b * n_hyp, 3), init_theta.reshape(b * n_hyp)
+                if init_principal is not None:
+                    init_principal = init_principal.reshape(-1, 2).expand(b, 2).repeat_interleave(n_hyp, dim=0)
         else:
             ds = kwargs.get("distance_source")
             init_C, init_theta, _ = get_init_pos(inter_module, cam_pos_pre_rendered, theta_pre_rendered, feature_map,
@@ -171,25 +193,36 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
                 all_C.append(C_[k * b:(k + 1) * b])
                 all_theta.append(th_[k * b:(k + 1) * b])
                 all_loss.append(loss_[k * b:(k + 1) * b])
-        use = torch.min(torch.stack(all_loss), dim=0)[1]
         ar = torch.arange(b, device=dev)
-        init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_theta)[use, ar]
-        init_principal = principal[use]
+        if n_hyp > 1:
+            if n_hyp > principal.shape[0]:
+                raise ValueError(f"hypotheses={n_hyp} exceeds the {principal.shape[0]} principal samples")
+            use = torch.sort(torch.stack(all_loss), dim=0, stable=True)[1][:n_hyp].T          # [b, K], best first
+            init_C = torch.stack(all_C)[use, ar[:, None]].reshape(b * n_hyp, 3)
+            init_theta = torch.stack(all_theta)[use, ar[:, None]].reshape(b * n_hyp)
+            init_principal = principal[use].reshape(b * n_hyp, 2)
+        else:
+            use = torch.min(torch.stack(all_loss), dim=0)[1]
+            init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_theta)[use, ar]
+            init_principal = principal[use]
         cams._N = b
     t2 = time.time()
     pred["pre_rendering_time"] = t2 - t1
 
     # Step 3: pose optimisation, all epochs on device
+    h2i = torch.arange(b, device=dev).repeat_interleave(n_hyp) if n_hyp > 1 else None
     if principal is not None and dof == 3:
-        init_C = init_C / init_C.pow(2).sum(-1).pow(.5)[..., None] * kwargs["distance_source"].to(dev)[..., None].float()
+        ds = kwargs["distance_source"].to(dev).float().reshape(-1).expand(b).repeat_interleave(n_hyp)
+        init_C = init_C / init_C.pow(2).sum(-1).pow(.5)[..., None] * ds[..., None]
     opt_dof = 6 if (dof == 6 or cfg.get("optimize_translation", False)) else dof
     cam = inter_module.camera()
     boxes = None
     if bbox is not None:
         rate = kwargs.get("down_sample_rate", 8)
         boxes = torch.tensor([[int(float(v) / rate + .5) for v in bbox[i][:4]] for i in range(b)], dtype=torch.int32)
+        boxes = boxes.repeat_interleave(n_hyp, dim=0)
     table = ops.similarity_table(inter_module.mesh, feature_map)
-    pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, init_principal, None,
+    pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, init_principal, h2i,
                         global_batch=kwargs.get("global_batch", b), dof=opt_dof, steps=epochs,
                         lr_every=epochs // 3 if epochs >= 3 else 0, score_boxes=boxes, **adam)
     sph = ops.spherical_angles(pose[:, 0:3])
@@ -199,10 +232,10 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
 
     preds = []
     for i in range(b):
-        r = host[i]
+        rows = host[i * n_hyp:(i + 1) * n_hyp]
         refined = [{
             "azimuth": float(r[10]), "elevation": float(r[9]), "theta": float(r[3]), "distance": float(r[8]),
             "principal": [float(r[4]), float(r[5])], "score": float(r[6]),
-        }]
+        } for r in rows[np.argsort(rows[:, 6], kind="stable")]]
         preds.append(dict(final=refined, **{k: pred[k] / b for k in pred.keys()}))
     return preds

@@ -256,6 +256,44 @@ def test_solve_pose_drop_in(small):
             assert k in preds[i]
 
 
+def test_solve_pose_multi_hypothesis(small):
+    """hypotheses=K: hypothesis 0 starts at the grid arg-min, so the K = 1 answer is among the K refined
+    poses bit for bit; every other one equals a lone solve started at its own grid pose; the list is
+    ordered by score."""
+    import nemo_amd
+    from nemo_amd import ops
+    from nemo_amd.utils import default_pose3d_config
+    sc = small
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    B, K = 3, 8
+    fm, gts = sc.feature_maps(B, first_seed=40)
+    fmd, clutter = fm.to(sc.device), sc.clutter.to(sc.device)
+    cfg = default_pose3d_config()
+    one = nemo_amd.solve_pose(cfg, fmd, sc.mod, clutter, cs, ths, maps, device=sc.device)
+    many = nemo_amd.solve_pose(cfg, fmd, sc.mod, clutter, cs, ths, maps, device=sc.device, hypotheses=K)
+    # the K starting poses
+    clu = ops.clutter_score(fmd, clutter)
+    loss, amin, _ = ops.grid_score(None, fmd, clu, packed=maps._nemo_packed_grid)
+    tab = ops.similarity_table(sc.mod.mesh, fmd)
+    for i in range(B):
+        fin = many[i]["final"]
+        assert len(fin) == K
+        scores = [f["score"] for f in fin]
+        assert scores == sorted(scores)
+        assert any(f == one[i]["final"][0] for f in fin), (i, one[i]["final"][0], fin)
+        assert fin[0]["score"] <= one[i]["final"][0]["score"]
+        order = torch.sort(loss[i], stable=True)[1][:K]
+        assert int(order[0]) == int(amin[i])
+        pose, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), tab[i:i + 1], clu[i:i + 1], cs[order], ths[order],
+                            hyp_to_image=torch.zeros(K, dtype=torch.int32), global_batch=B, steps=int(cfg.inference.epochs))
+        lone = sorted(float(s) for s in pose[:, 6].cpu())
+        assert lone == scores
+        assert R.pose_error(gts[i], fin[0]) * 180 / math.pi < 5.0
+    with pytest.raises(ValueError):
+        nemo_amd.solve_pose(cfg, fmd, sc.mod, clutter, cs, ths, maps, device=sc.device, hypotheses=10 ** 6)
+
+
 def test_global_batch_scaling(small):
     """A shard that passes the full batch size reproduces the full-batch result for its images."""
     from nemo_amd import ops
@@ -418,6 +456,13 @@ def test_solve_pose_6d(small):
         assert abs(got["principal"][0] - ref["principal"][0]) < 0.2 and abs(got["principal"][1] - ref["principal"][1]) < 0.2
         assert abs(got["score"] - ref["score"]) < 2e-3
         assert abs(got["principal"][0] - float(gt_pr[i, 0])) < 1.5 and abs(got["principal"][1] - float(gt_pr[i, 1])) < 1.5
+    # several hypotheses per image: the best pose of each of the K best principal samples
+    many = nemo_amd.solve_pose(cfg, fm.to(sc.device), sc.mod, sc.clutter.to(sc.device), cs, ths, maps, device=sc.device,
+                               principal=cand.to(sc.device), dof=6, hypotheses=3)
+    for i in range(B):
+        fin = many[i]["final"]
+        assert len(fin) == 3 and [f["score"] for f in fin] == sorted(f["score"] for f in fin)
+        assert any(f == preds[i]["final"][0] for f in fin)
 
 
 def test_dof6_first_steps_track_oracle(small):
