@@ -54,6 +54,7 @@ struct PoseCam {
     float sn, cs;                // sin, cos of theta
     int degenerate;
     int cull;                    // optimisation loop: faces looking away from the camera may be skipped this step
+    float qz0, qc;               // optimisation loop: start of the quantised depth range, and 2^23 - start in steps
 };
 
 __device__ inline void normalize3(float x, float y, float z, float* o, float* n_out) {

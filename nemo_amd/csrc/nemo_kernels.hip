@@ -261,6 +261,34 @@ static int plan_layout(int H, int W, int V, int F, int threads, LdsLayout* L) {
     return NEMO_OK;
 }
 
+// Layout and key format of the optimisation loop (make_solve_layout, depth_key32).
+static int plan_solve(int H, int W, int V, int F, int threads, const float* aabb, RasterCtx* rc) {
+    if (H > kMaxSide || W > kMaxSide || F >= kMaxFaces)
+        return fail(NEMO_ERR_UNSUPPORTED, "map %dx%d / %d faces exceed the rasteriser's limits (%d x %d pixels, %d faces)", H, W, F,
+                    kMaxSide, kMaxSide, kMaxFaces - 1);
+    const bool packable = V <= kPackedFaceVerts;
+    rc->L = make_solve_layout(H, W, V, F, packable, threads / 64);
+    if (!packable || rc->L.total > kMaxLds) rc->L = make_solve_layout(H, W, V, F, false, threads / 64);
+    if (rc->L.total > kMaxLds)
+        return fail(NEMO_ERR_UNSUPPORTED,
+                    "map %dx%d with %d vertices needs %d bytes of LDS per workgroup (limit %d)", H, W, V,
+                    rc->L.total, kMaxLds);
+    int fb = 9;                                    // at most 23 bits of depth: they are read from a float's mantissa
+    while ((1 << fb) <= F) ++fb;                   // 2^fb > F: no key equals the empty marker
+    rc->face_bits = fb;
+    float r2 = 0.0f;                               // bounding radius about the mesh origin: the farthest corner of the box
+    for (int c = 0; c < 8; ++c) {
+        float d2 = 0.0f;
+        for (int k = 0; k < 3; ++k) { const float x = aabb[(c >> k & 1) ? 3 + k : k]; d2 += x * x; }
+        r2 = d2 > r2 ? d2 : r2;
+    }
+    const float r = sqrtf(r2);
+    rc->depth_margin = 1.02f * r + 1e-6f;
+    rc->depth_qmax = (float)((1u << (32 - fb)) - 2u);
+    rc->depth_scale = rc->depth_qmax / (2.0f * rc->depth_margin);
+    return NEMO_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // projection (diagnostic / parity)
 // ------------------------------------------------------------------------------------------
@@ -822,8 +850,10 @@ struct SolveArgs {
 // WARP: the keypoint-initialised solver's translation model (solve_pose.py:258-276): parameters 4, 5 are a
 // 2-D flow; the map rendered at the default principal point is resampled bilinearly at pixel + flow / scale
 // (flow_warp.py: grid_sample, align_corners=True, border padding) before it is compared with the image.
+// Two workgroups per compute unit (four waves per SIMD, 128 registers): while one hypothesis is in a serial
+// section (pose set-up, the gradient chain, Adam) or waits on LDS, the other one's waves issue.
 template <bool FL, bool WARP>
-__global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
     const int h = blockIdx.x, tid = threadIdx.x;
@@ -832,7 +862,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
     const float* tab = a.table + (size_t)img * table_image_elems(V, HW);
     const int vg_n = (V + 3) >> 2;
     const float* clu = a.clu + (size_t)img * HW;
-    raster_prologue(a.rc, s);
+    solve_prologue(a.rc, s);
 
     // Adam's per-step constants (torch single-tensor path: bias corrections and step size in double, then
     // cast): step_size = -lr_k / (1 - beta1^(k+1)), sqrt(1 - beta2^(k+1)); lr_k follows the exponential schedule.
@@ -886,6 +916,8 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         __syncthreads();
     }
     const float fHW = (float)HW;
+    const unsigned int fmask = (1u << a.rc.face_bits) - 1u;
+    (void)fmask;
     // world vertices of this thread, resident in registers when the mesh is small enough
     const bool verts_resident = V <= kVertsPerThread * (int)blockDim.x;
     float wv[kVertsPerThread][3];
@@ -911,6 +943,10 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
                 outside = outside || os->P[k] < a.rc.aabb[k] - m || os->P[k] > a.rc.aabb[3 + k] + m;
             }
             s.pc->cull = a.rc.outward && outside;
+            // depth range of the keys: the vertices lie within the bounding radius of the mesh origin, whose view depth is T_z
+            const float z0 = s.pc->T[2] - a.rc.depth_margin;
+            s.pc->qz0 = z0;
+            s.pc->qc = 8388608.0f - z0 * a.rc.depth_scale;
         }
         __syncthreads();
         STAMP(0);
@@ -961,18 +997,18 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
                 const int x0 = (int)x0f, y0 = (int)y0f, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
                 const int qx[4] = {x0, x1, x0, x1}, qy[4] = {y0, y0, y1, y1};
                 const float wq[4] = {(1.0f - ax) * (1.0f - ay), ax * (1.0f - ay), (1.0f - ax) * ay, ax * ay};
-                unsigned long long key[4];
+                unsigned int key[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) key[k] = s.zbuf[qy[k] * W + qx[k]];
-                if (key[0] == kEmptyKey && key[1] == kEmptyKey && key[2] == kEmptyKey && key[3] == kEmptyKey) continue;
+                for (int k = 0; k < 4; ++k) key[k] = s.zkey[qy[k] * W + qx[k]];
+                if (key[0] == kEmptyKey32 && key[1] == kEmptyKey32 && key[2] == kEmptyKey32 && key[3] == kEmptyKey32) continue;
                 const float cl = clu[pt];
                 float sk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 float dd[4][3];
                 int vi[4][3];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (key[k] == kEmptyKey) continue;      // a source of weight 0 still enters the flow gradient
-                    load_face<FL>(a.rc, s, (int)(key[k] & 0xFFFFFFFFull), &vi[k][0], &vi[k][1], &vi[k][2]);
+                    if (key[k] == kEmptyKey32) continue;    // a source of weight 0 still enters the flow gradient
+                    load_face2<FL>(a.rc, s, (int)(key[k] & fmask), &vi[k][0], &vi[k][1], &vi[k][2]);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) dd[k][i] = tab[table_offset(vg_n, vi[k][i], pt)];
                     sk[k] = pixel_score(s.verts[vi[k][0]], s.verts[vi[k][1]], s.verts[vi[k][2]], s.xs[qx[k]], s.ys[qy[k]], dd[k]);
@@ -986,7 +1022,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
                 const float g = -mk * a.inv_norm;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (key[k] == kEmptyKey || wq[k] == 0.0f) continue;
+                    if (key[k] == kEmptyKey32 || wq[k] == 0.0f) continue;
                     (void)pixel_fused(cam_a, vinv.ia, vinv.bx, vinv.by, s.verts[vi[k][0]], s.verts[vi[k][1]], s.verts[vi[k][2]],
                                       s.xs[qx[k]], s.ys[qy[k]], dd[k], -__builtin_inff(), mk * a.inv_norm * wq[k], &acc);
                 }
@@ -998,9 +1034,8 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             vals[9] = acc.S[0]; vals[10] = acc.S[1]; vals[11] = acc.S[2];
             vals[12] = gfx * a.inv_tscale; vals[13] = gfy * a.inv_tscale; vals[14] = dmax; vals[15] = dbox;
         } else {
-        unsigned int* seg;
-        const int cnt = compact_covered(a.rc, s, &seg, row0, row1);
-        if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }   // all read before the barrier that ended the compaction
+        int first_chunk;
+        const int cnt = compact_covered32(a.rc, s, row0, row1, &first_chunk);
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
 #endif
@@ -1019,17 +1054,19 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
             // whose batch runs past the end re-reads its first entry with weight 0.
             constexpr int UNR = 1;
             const float cam_a = a.rc.cc.a;
-            for (int ib = tid & 63; ib < cnt; ib += 64 * UNR) {
+            static_assert(UNR == 1, "the entry slots are walked one chunk per trip");
+            unsigned int* slot = s.zkey + first_chunk * 64 + (tid & 63);        // entry j of this wave: chunk first_chunk + (j >> 6) * waves
+            const int slot_step = 64 * a.rc.L.waves;
+            for (int ib = tid & 63; ib < cnt; ib += 64 * UNR, slot += slot_step) {
                 int px[UNR], py[UNR], vi[UNR][3];
                 float dd[UNR][3], cc_[UNR], wg[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int idx = ib + u * 64;
-                    const bool ok = idx < cnt;
-                    wg[u] = ok ? 1.0f : 0.0f;
+                    wg[u] = 1.0f;
                     int f;
-                    unpack_entry(seg[ok ? idx : ib], &px[u], &py[u], &f);
-                    load_face<FL>(a.rc, s, f, &vi[u][0], &vi[u][1], &vi[u][2]);
+                    unpack_entry(*slot, &px[u], &py[u], &f);
+                    *slot = kEmptyKey32;                 // the slot is a key again: empty for the next step
+                    load_face2<FL>(a.rc, s, f, &vi[u][0], &vi[u][1], &vi[u][2]);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -1059,9 +1096,11 @@ __global__ __launch_bounds__(kSolveThreads) void solve_kernel(SolveArgs a) {
         block_sum16(vals, s.red, s.tot);
         STAMP(5);
         if (WARP)       // the key buffer was not consumed by a compaction: empty the rows that were drawn
-            for (int p = row0 * W + tid; p < row1 * W; p += blockDim.x) s.zbuf[p] = kEmptyKey;
+            for (int p = row0 * W + tid; p < row1 * W; p += blockDim.x) s.zkey[p] = kEmptyKey32;
 
         if (tid == 0) {
+            // every thread has read the row range (a barrier ago): back to "no rows", first face task = number of waves
+            if (!WARP) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }
             float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
             if (step == 0) os->first_loss = loss;
             os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
@@ -1128,7 +1167,7 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     a.rc.outward = m->faces_outward != nullptr;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kSolveThreads, &a.rc.L);
+    int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
     if (rcode) return rcode;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_principal;
@@ -1166,7 +1205,7 @@ extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const floa
     a.rc.outward = m->faces_outward != nullptr;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kSolveThreads, &a.rc.L);
+    int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
     if (rcode) return rcode;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_flow;

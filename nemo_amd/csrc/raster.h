@@ -28,7 +28,8 @@
 //   raster_direct      faces are handed out in tasks of 64 from an LDS counter; a lane orients its face's
 //                      edge functions, skips it when it looks away from a camera outside a closed solid,
 //                      and walks the pixel centres of its bounding box with incrementally stepped edge
-//                      functions and depth; same 64-bit atomic min.  No queue, no second pass.
+//                      functions and depth; 32-bit atomic min on (quantised depth << face bits | face).  No
+//                      queue, no second pass; the covered entries are compacted in place (compact_covered32).
 #pragma once
 #include "geom.h"
 
@@ -94,20 +95,53 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
     return L;
 }
 
+// Layout of the optimisation loop: 32-bit keys (quantised depth above the face index), the covered entries
+// are compacted in place into the key buffer (no queue) and a face is three 16-bit vertex indices.  Half the
+// size of the layout above, so that two workgroups share a compute unit.
+constexpr int kPackedFaceVerts = 1 << 16;     // faces are kept in LDS only when the vertex indices fit 16 bits
+inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds, int waves) {
+    LdsLayout L;
+    L.waves = waves;
+    const int chunks = (H * W + 63) / 64;
+    int o = 0;
+    L.zbuf = o; o = align16(o + 4 * 64 * chunks);      // whole chunks: entries may land in the padding of the last one
+    L.verts = o; o = align16(o + 16 * V);
+    if (faces_in_lds) { L.faces = o; o = align16(o + 8 * F); } else L.faces = -1;
+    L.xs = o; o = align16(o + 4 * W);
+    L.ys = o; o = align16(o + 4 * H);
+    L.queue = L.zbuf; L.qcap = 0; L.seg = 0;
+    L.red = o; o = align16(o + 4 * 16 * 16);
+    L.tot = o; o = align16(o + 4 * 16);
+    L.pc = o; o = align16(o + (int)sizeof(PoseCam));
+    L.opt = o; o = align16(o + 256);
+    L.sched = o; o = align16(o + 8 * kSchedSteps);
+    L.total = o;
+    return L;
+}
+
 struct RasterCtx {
     const float* verts;
     const int32_t* faces;
     int V, F;
     int outward;                // faces are wound counter-clockwise seen from outside a closed solid (optimisation loop only)
     float aabb[6];              // bounding box of the vertices
+    // optimisation loop: key = quantised depth << face_bits | face (see depth_key32)
+    int face_bits;              // 2^face_bits > F, at least 9
+    float depth_margin;         // view depths lie within T_z +- depth_margin (bounding radius of the vertices, plus slack)
+    float depth_scale;          // quantisation steps per unit of depth
+    float depth_qmax;           // largest quantised depth
     CamConst cc;
     LdsLayout L;
 };
 
+constexpr unsigned int kEmptyKey32 = 0xFFFFFFFFu;
+
 struct Lds {
     unsigned long long* zbuf;
+    unsigned int* zkey; // the same buffer as the 32-bit keys of the optimisation loop
     float4* verts;
     int4* faces;        // LDS copy or nullptr
+    uint2* faces2;      // the same area as packed faces (optimisation loop): x = i0 | i1 << 16, y = i2
     float *xs, *ys, *red, *tot;
     unsigned int* queue;
     unsigned int* qcount;    // [2]: pairs in the near half, pairs in the far half
@@ -118,8 +152,10 @@ struct Lds {
 __device__ inline Lds carve(char* base, const LdsLayout& L) {
     Lds s;
     s.zbuf = (unsigned long long*)(base + L.zbuf);
+    s.zkey = (unsigned int*)(base + L.zbuf);
     s.verts = (float4*)(base + L.verts);
     s.faces = L.faces >= 0 ? (int4*)(base + L.faces) : nullptr;
+    s.faces2 = L.faces >= 0 ? (uint2*)(base + L.faces) : nullptr;
     s.xs = (float*)(base + L.xs); s.ys = (float*)(base + L.ys);
     s.red = (float*)(base + L.red); s.tot = (float*)(base + L.tot);
     s.queue = (unsigned int*)(base + L.queue);
@@ -186,6 +222,27 @@ __device__ inline void raster_prologue(const RasterCtx& rc, const Lds& s) {
     if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s.red[i] = 0.0f;
     __syncthreads();      // the reduction scratch must be zero before any wave writes a partial into it
+}
+
+// The same for the layout of the optimisation loop (make_solve_layout).
+__device__ inline void solve_prologue(const RasterCtx& rc, const Lds& s) {
+    const int H = rc.cc.H, W = rc.cc.W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) s.xs[i] = pix_to_ndc(W - 1 - i, W, H);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s.ys[i] = pix_to_ndc(H - 1 - i, H, W);
+    if (s.faces2)
+        for (int i = threadIdx.x; i < rc.F; i += blockDim.x)
+            s.faces2[i] = make_uint2((unsigned)rc.faces[3 * i] | ((unsigned)rc.faces[3 * i + 1] << 16), (unsigned)rc.faces[3 * i + 2]);
+    const int slots = ((H * W + 63) >> 6) << 6;
+    for (int p = threadIdx.x; p < slots; p += blockDim.x) s.zkey[p] = kEmptyKey32;
+    if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s.red[i] = 0.0f;
+    __syncthreads();
+}
+
+template <bool FACES_LDS>
+__device__ inline void load_face2(const RasterCtx& rc, const Lds& s, int f, int* i0, int* i1, int* i2) {
+    if (FACES_LDS) { const uint2 t = s.faces2[f]; *i0 = t.x & 0xFFFFu; *i1 = t.x >> 16; *i2 = t.y; }
+    else { *i0 = rc.faces[3 * f + 0]; *i1 = rc.faces[3 * f + 1]; *i2 = rc.faces[3 * f + 2]; }
 }
 
 template <bool FACES_LDS>
@@ -516,7 +573,19 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
 // centres.  A lane steps two centres of its face per trip, straight-line code; the lanes of a wave leave
 // the loop when the largest box of the wave is done.  Faces with a vertex behind the camera take
 // the exact rule.  Key buffer must be empty on entry; ends with a barrier.
+//
+// Keys are 32 bits: the depth, quantised over the range the object can occupy this step (view depth of the
+// mesh origin +- the bounding radius), sits above the face index.  With 2000 faces that leaves 21 bits, a
+// step of about 1e-6 of the object's size: two faces compete for a pixel centre only when one occludes the
+// other (neighbours on a surface never both contain it), and then their depths differ by far more; closer
+// than a step, the smaller face index wins, as it does at equal depth with full-precision keys.
+// The quantised value is read from the mantissa of 2^23 + q, so it costs one fused multiply-add.
 #pragma clang fp contract(fast)
+__device__ inline unsigned int depth_key32(const RasterCtx& rc, float z0, float pz, int face) {
+    const float q = fminf(fmaxf((pz - z0) * rc.depth_scale, 0.0f), rc.depth_qmax);
+    return ((unsigned int)q << rc.face_bits) | (unsigned int)face;
+}
+
 struct WalkState {
     int n, nx, p, c, row_skip, face;
     float e0, e1, e2, su, a0, a1, a2, asu, r0, r1, r2, rsu, numer;
@@ -526,7 +595,7 @@ struct WalkGrid { int H, W; float dx, dy, x_org, y_org, inv_dx, inv_dy; };
 
 // Straight-line: every quantity is computed for every lane and the pixel count n is zeroed for faces
 // that are skipped.  Returns true for a face that needs the exact rule (a vertex behind the camera).
-__device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, bool cull, const FaceVerts& fv, WalkState* w, int* box) {
+__device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, bool cull, float zscale, const FaceVerts& fv, WalkState* w, int* box) {
     const int H = g.H, W = g.W;
     const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2), zmin = fminf(fminf(fv.z0, fv.z1), fv.z2);
     // signed area = e0 evaluated at vertex 0
@@ -570,15 +639,16 @@ __device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, bool cul
     w->su = w->e0 * z12 + w->e1 * z02 + w->e2 * z01;
     w->asu = w->a0 * z12 + w->a1 * z02 + w->a2 * z01;
     w->rsu = w->r0 * z12 + w->r1 * z02 + w->r2 * z01;
-    w->numer = (fv.z0 * z12) * fabsf(farea);
+    w->numer = (fv.z0 * z12) * fabsf(farea) * zscale;      // depth in quantisation steps = numer / su
     return slow;
 }
 
 // One pixel centre of the walk: test, depth, key, then step to the next centre (k = index of this centre).
-__device__ inline void walk_step(WalkState& w, int k, unsigned long long* zbuf) {
+// qc = 2^23 - (start of the depth range in steps): the sum is 2^23 + q, whose mantissa is the integer q.
+__device__ inline void walk_step(WalkState& w, int k, unsigned int* zkey, float qc, int face_bits) {
     const float lo = fminf(fminf(w.e0, w.e1), w.e2);
-    const float pz = w.numer * __builtin_amdgcn_rcpf(w.su);          // positive: every term of su has the sign of its e_i
-    if (lo > 0.0f && k < w.n) atomicMin(&zbuf[w.p], depth_key(pz, w.face));
+    const float t = __builtin_fmaf(w.numer, __builtin_amdgcn_rcpf(w.su), qc);   // su > 0 inside: every term has the sign of its e_i
+    if (lo > 0.0f && k < w.n) atomicMin(&zkey[w.p], (__float_as_uint(t) << face_bits) | (unsigned int)w.face);
     ++w.c;
     const bool wrap = w.c == w.nx;
     const float wf = wrap ? 1.0f : 0.0f;
@@ -606,6 +676,8 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     const int lane = threadIdx.x & 63;
     const int ntask = (rc.F + 63) >> 6;
     const bool cull = s.pc->cull != 0;          // set with the pose: outward faces and the camera outside the solid
+    const float qz0 = s.pc->qz0, qc = s.pc->qc; // depth range of this step
+    const int face_bits = rc.face_bits;
     int row_lo = g.H, row_hi = -1;              // pixel rows (yi) this thread's faces may touch
     int task = threadIdx.x >> 6;
     // the vertex records of the next task are requested before the pixel walk of the current one
@@ -613,7 +685,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     {
         const int f = task * 64 + lane;
         int i0 = 0, i1 = 0, i2 = 0;
-        if (f < rc.F) load_face<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+        if (f < rc.F) load_face2<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
         nfv = face_verts(s, i0, i1, i2);
     }
     while (task < ntask) {
@@ -625,25 +697,35 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
         {
             const int fn = next * 64 + lane;
             int i0 = 0, i1 = 0, i2 = 0;
-            if (fn < rc.F) load_face<FACES_LDS>(rc, s, fn, &i0, &i1, &i2);
+            if (fn < rc.F) load_face2<FACES_LDS>(rc, s, fn, &i0, &i1, &i2);
             nfv = face_verts(s, i0, i1, i2);
         }
         WalkState w;
         int box[4];
-        const bool slow = walk_setup(g, f, f < rc.F, cull, fv, &w, box);
+        const bool slow = walk_setup(g, f, f < rc.F, cull, rc.depth_scale, fv, &w, box);
         if (w.n > 0 || slow) { row_lo = min(row_lo, g.H - 1 - box[3]); row_hi = max(row_hi, g.H - 1 - box[1]); }
         if (__any(slow)) {                       // rare: a face crossing the camera plane
             if (slow)
                 for (int jy = box[1]; jy <= box[3]; ++jy)
-                    for (int jx = box[0]; jx <= box[2]; ++jx) eval_pair<true>(f, fv, g.W - 1 - jx, g.H - 1 - jy, g.W, s);
+                    for (int jx = box[0]; jx <= box[2]; ++jx) {
+                        const int xi = g.W - 1 - jx, yi = g.H - 1 - jy;
+                        const float xf = s.xs[xi], yf = s.ys[yi];
+                        const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
+                        const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
+                        if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+                        float b[3], pz;
+                        face_eval(fv, xf, yf, b, &pz);
+                        if (pz < 0.0f || !(b[0] > 0.0f && b[1] > 0.0f && b[2] > 0.0f)) continue;
+                        atomicMin(&s.zkey[yi * g.W + xi], depth_key32(rc, qz0, pz, f));
+                    }
         }
         P1STAMP(0);
         for (int k = 0; __any(k < w.n); k += 2) {
 #ifdef NEMO_STAMPS_P1
             ++iters;
 #endif
-            walk_step(w, k, s.zbuf);
-            walk_step(w, k + 1, s.zbuf);
+            walk_step(w, k, s.zkey, qc, face_bits);
+            walk_step(w, k + 1, s.zkey, qc, face_bits);
         }
         P1STAMP(1);
         task = next;
@@ -755,6 +837,46 @@ __device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigne
     }
     __syncthreads();
     *seg_out = seg;
+    return count;
+}
+
+// Optimisation loop: the same compaction for 32-bit keys, in place.  Wave w owns the chunks c0 + w,
+// c0 + w + waves, ... of the touched rows; its j-th covered entry is written over the j-th slot of those
+// same chunks (slot j lives at chunk c0 + w + (j >> 6) * waves, lane j & 63), which it has already read:
+// the key buffer doubles as the entry list and no other wave touches these chunks before the next step.
+// The caller consumes the entries with the same slot arithmetic and leaves every slot empty again.
+// Returns the number of entries; *first_chunk = c0 + w.  No barrier.
+__device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int row0, int row1, int* first_chunk) {
+    const int W = rc.cc.W, nw = rc.L.waves;
+    const int c0 = (row0 * W) >> 6, c1 = (row1 * W + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int fmask = (1u << rc.face_bits) - 1u;
+    const float inv_w = 1.0f / (float)W;
+    const int cw = c0 + wave;
+    int count = 0;
+    constexpr int CB = 4;                       // chunks in flight per wave: their key reads overlap
+    for (int cb = cw; cb < c1; cb += CB * nw) {
+        unsigned int key[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int c = cb + u * nw;
+            key[u] = c < c1 ? s.zkey[c * 64 + lane] : kEmptyKey32;      // the padding of the last chunk stays empty
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int p = (cb + u * nw) * 64 + lane;
+            const bool cov = key[u] != kEmptyKey32;
+            const unsigned long long m = __ballot(cov);
+            if (cov) {
+                s.zkey[p] = kEmptyKey32;        // before the entry writes below: LDS accesses of a wave stay in order
+                const int j = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                const int yi = (int)(((float)p + 0.5f) * inv_w);       // exact for p < 2^22
+                s.zkey[(cw + (j >> 6) * nw) * 64 + (j & 63)] = pack_entry(p - yi * W, yi, (int)(key[u] & fmask));
+            }
+            count += __popcll(m);
+        }
+    }
+    *first_chunk = cw;
     return count;
 }
 
