@@ -98,8 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 2: 64)")
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="batches processed together (a 64-image solve launch occupies 64 of the 256 CUs; four batches "
+    ap.add_argument("--in-flight", type=int, default=8,
+                    help="batches processed together (a 64-image solve launch occupies an eighth of the chip; eight batches "
                          "in flight fill the chip); every batch keeps its own loss normaliser")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -230,7 +230,7 @@ def main():
         # HBM-side traffic of the same launch shape, from the committed rocprofv3 --pmc passes (bench.py cannot
         # run the profiler on itself); None when the launch shape differs from the profiled one.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_solve_traffic_v3.json")
+        tpath = os.path.join(ROOT, "profiles", "r1_solve_traffic_v4.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
@@ -252,7 +252,7 @@ def main():
             "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": G * B * EPOCHS * ALGO_BYTES_PER_HYP_STEP,
-                         "traffic_source": "profiles/r1_solve_traffic_v3.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
+                         "traffic_source": "profiles/r1_solve_traffic_v4.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
                          "note": "achieved = 300 steps x hypotheses per launch x 4.128 MB (one read of the image's feature map + clutter "
                                  "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
                                  "kernel reads a precomputed vertex x pixel similarity table instead (3 floats per covered pixel), "

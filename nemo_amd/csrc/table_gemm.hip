@@ -149,7 +149,7 @@ int launch_table_gemm(const float* memT, const float* feat, float* table, int V,
 // split-f16 path
 // ---------------------------------------------------------------------------------------------
 constexpr int SG_PT = 128;          // pixels per workgroup
-constexpr int SG_THREADS = 256;     // 4 waves: 2 (vertex blocks of 64) x 2 (pixel blocks of 64)
+constexpr int SG_THREADS = 256;     // 4 waves, each a 32-vertex block x all 128 pixels at a time
 
 // Header of the bank fragment buffer (first 256 bytes): largest |memory| as float bits, the power-of-two
 // scale applied to the bank, and the factor that undoes both scales on the result.
@@ -194,24 +194,21 @@ __global__ void split_bank_kernel(const float* __restrict__ memory, BankMeta* me
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Stores register quads [J0, J1) of the four accumulator tiles of one wave into its pixel tile of the
-// table (tile: [vertex group][128 pixels] 16-byte elements; col = the lane's first pixel column, the
-// second is col + 32).  A quad is four consecutive vertices of one pixel = one element, so a store
-// instruction writes two contiguous 512-byte runs.  CHECK = false: the caller guarantees that all 64
-// rows exist, and the stores are straight-line code.
+// Stores register quads [J0, J1) of the four accumulator tiles of one wave (32 vertices x 4 blocks of 32
+// pixels) into its pixel tile of the table (tile: [vertex group][128 pixels] 16-byte elements).  A quad is
+// four consecutive vertices of one pixel = one element, so a store instruction writes two contiguous
+// 512-byte runs (vertex groups 2j and 2j + 1 of the block), and the 16 stores of a wave-tile fill 16
+// contiguous kilobytes.  CHECK = false: the caller guarantees that all 32 rows exist, and the stores are
+// straight-line code.  Plain stores: measured faster than non-temporal ones for this pattern.
 template <int J0, int J1, bool CHECK>
-__device__ inline void store_quads(f32x4* __restrict__ tile, const f32x16& c00, const f32x16& c01, const f32x16& c10,
-                                   const f32x16& c11, int v0, int vg_n, int lk, int col, float us) {
+__device__ inline void store_quads(f32x4* __restrict__ tile, const f32x16 (&c)[4], int v0, int vg_n, int lk, int px, float us) {
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
-        const int g0 = (v0 >> 2) + 2 * j + lk, g1 = g0 + 8;
-        if (!CHECK || g0 < vg_n) {
-            __builtin_nontemporal_store((f32x4){c00[4 * j] * us, c00[4 * j + 1] * us, c00[4 * j + 2] * us, c00[4 * j + 3] * us}, tile + g0 * SG_PT + col);
-            __builtin_nontemporal_store((f32x4){c01[4 * j] * us, c01[4 * j + 1] * us, c01[4 * j + 2] * us, c01[4 * j + 3] * us}, tile + g0 * SG_PT + col + 32);
-        }
-        if (!CHECK || g1 < vg_n) {
-            __builtin_nontemporal_store((f32x4){c10[4 * j] * us, c10[4 * j + 1] * us, c10[4 * j + 2] * us, c10[4 * j + 3] * us}, tile + g1 * SG_PT + col);
-            __builtin_nontemporal_store((f32x4){c11[4 * j] * us, c11[4 * j + 1] * us, c11[4 * j + 2] * us, c11[4 * j + 3] * us}, tile + g1 * SG_PT + col + 32);
+        const int g = (v0 >> 2) + 2 * j + lk;
+        if (!CHECK || g < vg_n) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                tile[g * SG_PT + t * 32 + px] = (f32x4){c[t][4 * j] * us, c[t][4 * j + 1] * us, c[t][4 * j + 2] * us, c[t][4 * j + 3] * us};
         }
     }
 }
@@ -219,68 +216,64 @@ __device__ inline void store_quads(f32x4* __restrict__ tile, const f32x16& c00, 
 template <int NKS>
 struct SplitWave {
     const uint4* bank_frag; const char* bbase; f32x4* tile;
-    size_t apiece; int vg_n, lane, lk, col; float unscale;
+    size_t apiece; int vg_n, lane, lk, px; float unscale;
     static constexpr int C = NKS * 16;
     static constexpr int row_bytes = C * 2 + 16;      // +16: consecutive pixels start 4 banks apart
     static constexpr int piece_bytes = SG_PT * row_bytes;
     static constexpr int QPK = (4 + NKS - 1) / NKS;   // result register quads stored per k-step
 
     template <int KS>
-    __device__ inline void store_slice(const f32x16& o00, const f32x16& o01, const f32x16& o10, const f32x16& o11, int v0) const {
+    __device__ inline void store_slice(const f32x16 (&o)[4], int v0) const {
         constexpr int J0 = KS * QPK < 4 ? KS * QPK : 4, J1 = (KS + 1) * QPK < 4 ? (KS + 1) * QPK : 4;
-        store_quads<J0, J1, false>(tile, o00, o01, o10, o11, v0, vg_n, lk, col, unscale);
+        store_quads<J0, J1, false>(tile, o, v0, vg_n, lk, px, unscale);
     }
 
-    // One 64 x 64 result tile (vertex blocks vb0, vb0 + 1).  The A fragments of k-step ks+1 are requested
-    // before the MFMAs of k-step ks.  STORE_PREV: the 16 stores of the previous tile (o.., all of it
-    // inside the table) are spread over the k-steps, each slice issued after the A request, so that
-    // waiting for the fragments never waits for a store (gfx9 counts loads and stores in one in-order
-    // counter).
+    // One 32 x 128 result tile: vertex block vb against the whole pixel tile, so a bank fragment is fetched
+    // by exactly one wave of the workgroup.  The A fragments are requested two k-steps ahead of
+    // their MFMAs.  STORE_PREV: the 16 stores of the previous tile (o, all of it inside the table) are
+    // spread over the k-steps, each slice issued after the A request, so that waiting for the fragments
+    // never waits for a store (gfx9 counts loads and stores in one in-order counter).
     template <bool STORE_PREV>
-    __device__ inline void tile_mma(int vb0, f32x16& acc00, f32x16& acc01, f32x16& acc10, f32x16& acc11, const f32x16& o00,
-                                const f32x16& o01, const f32x16& o10, const f32x16& o11, int prev_v0) const {
-        const uint4* a0p = bank_frag + ((size_t)vb0 * NKS) * 64 + lane;
-        const uint4* a1p = a0p + (size_t)NKS * 64;
-        uint4 na0[SG_NP], na1[SG_NP];
+    __device__ inline void tile_mma(int vb, f32x16 (&acc)[4], const f32x16 (&o)[4], int prev_v0) const {
+        const uint4* ap = bank_frag + ((size_t)vb * NKS) * 64 + lane;
+        constexpr int PF = NKS > 1 ? 2 : 1;      // k-steps of A fragments in flight: an L2 round trip outlasts one step's MFMAs
+        uint4 na[PF][SG_NP];
 #pragma unroll
-        for (int pc = 0; pc < SG_NP; ++pc) { na0[pc] = a0p[pc * apiece]; na1[pc] = a1p[pc * apiece]; }
+        for (int d = 0; d < PF; ++d)
+#pragma unroll
+            for (int pc = 0; pc < SG_NP; ++pc) na[d][pc] = ap[pc * apiece + (size_t)(d < NKS ? d : 0) * 64];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            f16x8 a0[SG_NP], a1[SG_NP], b0[SG_NP], b1[SG_NP];
+            f16x8 a[SG_NP], b[4][SG_NP];
 #pragma unroll
-            for (int pc = 0; pc < SG_NP; ++pc) { a0[pc] = as_frag(na0[pc]); a1[pc] = as_frag(na1[pc]); }
-            if (ks + 1 < NKS) {
+            for (int pc = 0; pc < SG_NP; ++pc) a[pc] = as_frag(na[ks % PF][pc]);
+            if (ks + PF < NKS) {
 #pragma unroll
-                for (int pc = 0; pc < SG_NP; ++pc) {
-                    na0[pc] = a0p[pc * apiece + (size_t)(ks + 1) * 64];
-                    na1[pc] = a1p[pc * apiece + (size_t)(ks + 1) * 64];
-                }
+                for (int pc = 0; pc < SG_NP; ++pc) na[ks % PF][pc] = ap[pc * apiece + (size_t)(ks + PF) * 64];
             }
 #pragma unroll
-            for (int pc = 0; pc < SG_NP; ++pc) {
-                b0[pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + ks * 32));
-                b1[pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + 32 * row_bytes + ks * 32));
-            }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int pc = 0; pc < SG_NP; ++pc)
+                    b[t][pc] = as_frag(*reinterpret_cast<const uint4*>(bbase + pc * piece_bytes + t * 32 * row_bytes + ks * 32));
             if (STORE_PREV) {
                 switch (ks) {          // ks is a compile-time constant after unrolling
-                    case 0: store_slice<0>(o00, o01, o10, o11, prev_v0); break;
-                    case 1: store_slice<1>(o00, o01, o10, o11, prev_v0); break;
-                    case 2: store_slice<2>(o00, o01, o10, o11, prev_v0); break;
-                    case 3: store_slice<3>(o00, o01, o10, o11, prev_v0); break;
-                    case 4: store_slice<4>(o00, o01, o10, o11, prev_v0); break;
-                    case 5: store_slice<5>(o00, o01, o10, o11, prev_v0); break;
-                    case 6: store_slice<6>(o00, o01, o10, o11, prev_v0); break;
-                    default: store_slice<7>(o00, o01, o10, o11, prev_v0); break;
+                    case 0: store_slice<0>(o, prev_v0); break;
+                    case 1: store_slice<1>(o, prev_v0); break;
+                    case 2: store_slice<2>(o, prev_v0); break;
+                    case 3: store_slice<3>(o, prev_v0); break;
+                    case 4: store_slice<4>(o, prev_v0); break;
+                    case 5: store_slice<5>(o, prev_v0); break;
+                    case 6: store_slice<6>(o, prev_v0); break;
+                    default: store_slice<7>(o, prev_v0); break;
                 }
             }
             // piece pairs in increasing weight: (l,h) (h,l) (h,h)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int ia = q == 0 ? 1 : 0, ib = q == 1 ? 1 : 0;
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ia], b0[ib], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ia], b1[ib], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ia], b0[ib], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ia], b1[ib], acc11, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ia], b[t][ib], acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);        // keep the k-steps apart: registers for one step's operands only
         }
@@ -289,7 +282,7 @@ struct SplitWave {
 
 // NKS = C / 16 k-steps, fully unrolled.
 template <int NKS>
-__global__ __launch_bounds__(SG_THREADS, 2) void split_table_kernel(const BankMeta* __restrict__ meta,
+__global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const BankMeta* __restrict__ meta,
                                                                     const uint4* __restrict__ bank_frag,
                                                                     const float* __restrict__ feat, float* __restrict__ table,
                                                                     int V, int nvb, int HW, int npt) {
@@ -334,36 +327,36 @@ __global__ __launch_bounds__(SG_THREADS, 2) void split_table_kernel(const BankMe
     }
     __syncthreads();
 
-    // ---- phase 2: all vertex blocks against the resident pixel tile ----
-    const int wr = wave >> 1, wc = wave & 1;          // wr in 0..1
+    // ---- phase 2: this wave's vertex blocks (wave, wave + 4, ...) against the resident pixel tile ----
     W w;
     w.unscale = meta->unscale;
-    w.bank_frag = bank_frag; w.lane = lane; w.lk = lane >> 5;
-    w.bbase = sg_lds + (wc * 64 + (lane & 31)) * row_bytes + w.lk * 16;
+    w.bank_frag = bank_frag; w.lane = lane; w.lk = lane >> 5; w.px = lane & 31;
+    w.bbase = sg_lds + (lane & 31) * row_bytes + w.lk * 16;
     w.vg_n = (V + 3) >> 2;
     w.tile = reinterpret_cast<f32x4*>(table) + ((size_t)b * npt + pt) * w.vg_n * SG_PT;
     w.apiece = (size_t)nvb * NKS * 64;
-    w.col = wc * 64 + (lane & 31);
 
-    int vb0 = wr * 2;                                  // nvb is even: blocks vb0 and vb0 + 1 both exist
-    if (vb0 >= nvb) return;
-    // Only the last tile of a wave can hang over the end of the vertex list, and the last tile is stored
-    // by the checked epilogue: every tile stored inside the pipelined loop is complete.  Pixel columns
-    // past HW exist in the table (zero features give zeros).
-    f32x16 o00 = {0}, o01 = {0}, o10 = {0}, o11 = {0};
+    int vb = wave;
+    if (vb >= nvb) return;
+    // The vertex list ends less than 64 rows before the end of the last block pair, so only the last block
+    // of a wave can hang over it, and the last block is stored by the checked epilogue: every block stored
+    // inside the pipelined loop is complete.  Pixel columns past HW exist in the table (zero features give zeros).
+    f32x16 o[4] = {};
     {
-        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-        w.template tile_mma<false>(vb0, acc00, acc01, acc10, acc11, o00, o01, o10, o11, 0);
-        o00 = acc00; o01 = acc01; o10 = acc10; o11 = acc11;
+        f32x16 acc[4] = {};
+        w.template tile_mma<false>(vb, acc, o, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acc[k];
     }
-    int prev_v0 = vb0 * 32;
-    for (vb0 += 4; vb0 < nvb; vb0 += 4) {
-        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-        w.template tile_mma<true>(vb0, acc00, acc01, acc10, acc11, o00, o01, o10, o11, prev_v0);
-        o00 = acc00; o01 = acc01; o10 = acc10; o11 = acc11;
-        prev_v0 = vb0 * 32;
+    int prev_v0 = vb * 32;
+    for (vb += SG_THREADS / 64; vb < nvb; vb += SG_THREADS / 64) {
+        f32x16 acc[4] = {};
+        w.template tile_mma<true>(vb, acc, o, prev_v0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acc[k];
+        prev_v0 = vb * 32;
     }
-    store_quads<0, 4, true>(w.tile, o00, o01, o10, o11, prev_v0, w.vg_n, w.lk, w.col, w.unscale);
+    store_quads<0, 4, true>(w.tile, o, prev_v0, w.vg_n, w.lk, w.px, w.unscale);
 }
 
 bool split_table_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128; }
