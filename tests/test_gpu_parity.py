@@ -718,6 +718,53 @@ def test_solve_on_rewound_and_open_meshes(gpu, variant):
     assert rel_err(pose[:, 0:3].cpu(), Cr) < 2e-4
 
 
+def test_solve_camera_inside_bounding_sphere(small):
+    """Cameras so close that some vertices lie behind the camera plane: those faces take the exact rule and
+    their depths fall outside the quantised key range (clamped); the first steps still track the oracle."""
+    from nemo_amd import ops
+    sc = small
+    fm, _ = sc.feature_maps(2, first_seed=7)
+    clu = R.clutter_score(fm, sc.clutter)
+    C0 = torch.tensor([[0.0, 0.36, 0.27], [0.30, 0.10, 0.35]])
+    th0 = torch.tensor([0.1, -0.2])
+    Xv = R.project_verts(sc.ref.verts, C0, th0, sc.cam)[3]
+    assert bool((Xv[2] < 0).any()) and bool((Xv[2] > 0).any()), "the test wants vertices on both sides of the camera plane"
+    steps = 3
+    Cr, thr, _, scores, hist = R.optimize_poses(sc.ref, fm, clu, C0, th0, None, 3, epochs=steps, record=True)
+    tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
+    pose, lh = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu.to(sc.device), C0.to(sc.device), th0.to(sc.device),
+                         steps=steps, history=True)
+    per_image = torch.stack([h["per_image"] for h in hist], dim=1)
+    assert rel_err(lh[:, 0], per_image[:, 0]) < REL
+    assert rel_err(lh.cpu(), per_image) < 1e-3
+    assert rel_err(pose[:, 0:3], Cr) < 1e-3
+
+
+def test_solve_faces_read_from_global_memory(gpu):
+    """A mesh whose vertex records and packed faces do not fit the 160 KB of LDS together: the kernel keeps the
+    vertices in LDS and reads the faces from global memory.  Sub-pixel faces on a small map."""
+    from nemo_amd import ops
+    sc = Scene(32, 40, 16, 5200, 150.0, device=gpu, n_clutter=16)
+    V, F, HW = sc.verts.shape[0], sc.faces.shape[0], sc.H * sc.W
+    assert 4 * 64 * ((HW + 63) // 64) + 16 * V + 8 * F > 160 * 1024 > 4 * 64 * ((HW + 63) // 64) + 16 * V + 8192
+    fm, gts = sc.feature_maps(2, first_seed=3)
+    clu = R.clutter_score(fm, sc.clutter)
+    g = torch.Generator().manual_seed(5)
+    az = torch.tensor([t["azimuth"] for t in gts]) + 0.2 * (torch.rand(2, generator=g) - 0.5)
+    el = torch.tensor([t["elevation"] for t in gts]) + 0.2 * (torch.rand(2, generator=g) - 0.5)
+    th0 = (torch.tensor([t["theta"] for t in gts]) + 0.2 * (torch.rand(2, generator=g) - 0.5)).float()
+    C0 = R.camera_position_from_spherical_angles(5.0, el, az)
+    steps = 4
+    Cr, thr, _, scores, hist = R.optimize_poses(sc.ref, fm, clu, C0, th0, None, 3, epochs=steps, record=True)
+    tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
+    pose, lh = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu.to(sc.device), C0.to(sc.device), th0.to(sc.device),
+                         steps=steps, history=True)
+    per_image = torch.stack([h["per_image"] for h in hist], dim=1)
+    assert rel_err(lh, per_image) < REL
+    assert rel_err(pose[:, 0:3], Cr) < 1e-4
+    assert float((pose[:, 3].cpu() - thr).abs().max()) < 1e-4
+
+
 def test_grid_pack_falls_back_for_other_channel_counts(gpu):
     """The matrix-core scoring takes 16/32/64/128 channels; any other count scores through the VALU kernel,
     and solve_pose's helper picks whichever applies."""
