@@ -878,6 +878,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     if (tid == 0) {
         s.qcount[0] = (unsigned)H; s.qcount[1] = 0u;       // row range of the covered pixels (see raster_direct)
         s.qcount[2] = kSolveThreads / 64;                  // next face task
+        s.qcount[3] = 0u;                                  // length of the front-face list
         for (int k = 0; k < 6; ++k) { os->m[k] = 0.0f; os->v[k] = 0.0f; }
         os->P[0] = a.init_campos[3 * h]; os->P[1] = a.init_campos[3 * h + 1]; os->P[2] = a.init_campos[3 * h + 2];
         os->P[3] = a.init_theta[h];
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         STAMP(1);
         raster_direct<FL>(a.rc, s);
 #ifdef NEMO_STAMPS_P1
-        if (tid == 0 && a.out_hist) for (int k = 0; k < 3; ++k) a.out_hist[(size_t)h * a.steps + 8 + k] += s.tot[k] / (float)a.steps;
+        if (tid == 0 && a.out_hist) for (int k = 0; k < 6; ++k) a.out_hist[(size_t)h * a.steps + 16 + k] += s.tot[k] / (float)a.steps;
 #endif
         STAMP(7);
 #ifdef NEMO_STAMPS_P1
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             const float fnx = (os->P[4] / tscale) / (((float)W - 1.0f) / 2.0f), fny = (os->P[5] / tscale) / (((float)H - 1.0f) / 2.0f);
             const float stepx = 2.0f / (float)(W - 1), stepy = 2.0f / (float)(H - 1);
             __syncthreads();                    // everyone has read the row range and the flow
-            if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }
+            if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u; }
             PixelGrad acc;
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 
         if (tid == 0) {
             // every thread has read the row range (a barrier ago): back to "no rows", first face task = number of waves
-            if (!WARP) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; }
+            if (!WARP) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u; }
             float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
             if (step == 0) os->first_loss = loss;
             os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;

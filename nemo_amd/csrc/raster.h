@@ -66,6 +66,7 @@ struct LdsLayout {
     int pc;                     // PoseCam
     int opt;                    // optimiser state (solve kernel) + queue counter
     int sched;                  // float2 [kSchedSteps]: per-step Adam step size and sqrt of the second bias correction
+    int flist;                  // u16 [F]: faces that look at the camera this step (optimisation loop; -1: not kept)
     int total;
 };
 
@@ -91,6 +92,7 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
     L.pc = o; o = align16(o + (int)sizeof(PoseCam));
     L.opt = o; o = align16(o + 256);
     L.sched = o; o = align16(o + 8 * kSchedSteps);
+    L.flist = -1;
     L.total = o;
     return L;
 }
@@ -115,6 +117,7 @@ inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds
     L.pc = o; o = align16(o + (int)sizeof(PoseCam));
     L.opt = o; o = align16(o + 256);
     L.sched = o; o = align16(o + 8 * kSchedSteps);
+    if (F < (1 << 16)) { L.flist = o; o = align16(o + 2 * F); } else L.flist = -1;
     L.total = o;
     return L;
 }
@@ -144,7 +147,8 @@ struct Lds {
     uint2* faces2;      // the same area as packed faces (optimisation loop): x = i0 | i1 << 16, y = i2
     float *xs, *ys, *red, *tot;
     unsigned int* queue;
-    unsigned int* qcount;    // [2]: pairs in the near half, pairs in the far half
+    unsigned int* qcount;    // [4]: render kernels: pairs in the near / far half; optimisation loop: row range, task counter, front faces
+    unsigned short* flist;   // optimisation loop: front-face list or nullptr
     PoseCam* pc;
     char* opt;
 };
@@ -162,6 +166,7 @@ __device__ inline Lds carve(char* base, const LdsLayout& L) {
     s.pc = (PoseCam*)(base + L.pc);
     s.opt = base + L.opt;
     s.qcount = (unsigned int*)(base + L.opt + 240);
+    s.flist = L.flist >= 0 ? (unsigned short*)(base + L.flist) : nullptr;
     return s;
 }
 
@@ -658,9 +663,15 @@ __device__ inline void walk_step(WalkState& w, int k, unsigned int* zkey, float 
     w.c = wrap ? 0 : w.c;
 }
 
-// Work is handed out in tasks of 64 consecutive faces (one per lane): a wave starts with task = its
+// When back faces can be skipped (closed solid, camera outside) a first pass over all faces lists the ones
+// that look at the camera (signed screen area > 0), so that the walk below runs on lanes that all hold a
+// face with work: about half the faces of a solid look away.  The list order depends on which wave adds
+// its faces first, which the atomic-min key buffer does not care about.
+//
+// Work is handed out in tasks of 64 consecutive (listed) faces (one per lane): a wave starts with task = its
 // index and takes the next one from an LDS counter (s.qcount[2], which the caller keeps at the number
-// of waves between steps), so waves whose faces have small boxes pick up more tasks.
+// of waves between steps), so waves whose faces have small boxes pick up more tasks.  The caller keeps
+// s.qcount[3] (length of the list) at 0 between steps.
 template <bool FACES_LDS>
 __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     WalkGrid g;
@@ -674,35 +685,71 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     int iters = 0;
 #endif
     const int lane = threadIdx.x & 63;
-    const int ntask = (rc.F + 63) >> 6;
     const bool cull = s.pc->cull != 0;          // set with the pose: outward faces and the camera outside the solid
     const float qz0 = s.pc->qz0, qc = s.pc->qc; // depth range of this step
     const int face_bits = rc.face_bits;
+    const bool listed = cull && s.flist != nullptr;
+    int nfaces = rc.F;
+    if (listed) {
+        for (int base = 0; base < rc.F; base += blockDim.x) {
+            const int f = base + threadIdx.x;
+            bool front = false;
+            if (f < rc.F) {
+                int i0, i1, i2;
+                load_face2<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+                const float2 a = *reinterpret_cast<const float2*>(&s.verts[i0]), b = *reinterpret_cast<const float2*>(&s.verts[i1]),
+                             c = *reinterpret_cast<const float2*>(&s.verts[i2]);
+                front = (c.y - b.y) * (a.x - b.x) + (b.x - c.x) * (a.y - b.y) > 0.0f;      // the signed area of walk_setup
+            }
+            const unsigned long long m = __ballot(front);
+            if (m) {
+                unsigned int off = 0;
+                if (lane == 0) off = atomicAdd(&s.qcount[3], (unsigned)__popcll(m));
+                off = __builtin_amdgcn_readfirstlane(off);
+                if (front) s.flist[off + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (unsigned short)f;
+            }
+        }
+        __syncthreads();
+        nfaces = (int)s.qcount[3];
+    }
+#ifdef NEMO_STAMPS_P1
+    { long long t_ = clock64(); tq[2] = t_ - tq0; tq0 = t_; }
+    int ntasks_done = 0;
+#endif
+    const int ntask = (nfaces + 63) >> 6;
     int row_lo = g.H, row_hi = -1;              // pixel rows (yi) this thread's faces may touch
     int task = threadIdx.x >> 6;
     // the vertex records of the next task are requested before the pixel walk of the current one
     FaceVerts nfv;
+    int nf = 0;
     {
-        const int f = task * 64 + lane;
+        const int idx = task * 64 + lane;
         int i0 = 0, i1 = 0, i2 = 0;
-        if (f < rc.F) load_face2<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+        if (idx < nfaces) {
+            nf = listed ? (int)s.flist[idx] : idx;
+            load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
+        }
         nfv = face_verts(s, i0, i1, i2);
     }
     while (task < ntask) {
-        const int f = task * 64 + lane;
+        const bool valid = task * 64 + lane < nfaces;
+        const int f = nf;
         const FaceVerts fv = nfv;
         unsigned int nt = 0;
         if (lane == 0) nt = atomicAdd(&s.qcount[2], 1u);
         const int next = (int)__builtin_amdgcn_readfirstlane(nt);
         {
-            const int fn = next * 64 + lane;
+            const int idx = next * 64 + lane;
             int i0 = 0, i1 = 0, i2 = 0;
-            if (fn < rc.F) load_face2<FACES_LDS>(rc, s, fn, &i0, &i1, &i2);
+            if (idx < nfaces) {
+                nf = listed ? (int)s.flist[idx] : idx;
+                load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
+            }
             nfv = face_verts(s, i0, i1, i2);
         }
         WalkState w;
         int box[4];
-        const bool slow = walk_setup(g, f, f < rc.F, cull, rc.depth_scale, fv, &w, box);
+        const bool slow = walk_setup(g, f, valid, cull, rc.depth_scale, fv, &w, box);
         if (w.n > 0 || slow) { row_lo = min(row_lo, g.H - 1 - box[3]); row_hi = max(row_hi, g.H - 1 - box[1]); }
         if (__any(slow)) {                       // rare: a face crossing the camera plane
             if (slow)
@@ -728,10 +775,13 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
             walk_step(w, k + 1, s.zkey, qc, face_bits);
         }
         P1STAMP(1);
+#ifdef NEMO_STAMPS_P1
+        ++ntasks_done;
+#endif
         task = next;
     }
 #ifdef NEMO_STAMPS_P1
-    if (threadIdx.x == 64) { s.tot[0] = (float)tq[0]; s.tot[1] = (float)tq[1]; s.tot[2] = (float)iters; }
+    if (threadIdx.x == 64) { s.tot[0] = (float)tq[0]; s.tot[1] = (float)tq[1]; s.tot[2] = (float)iters; s.tot[3] = (float)tq[2]; s.tot[4] = (float)ntasks_done; s.tot[5] = (float)nfaces; }
 #endif
     // rows that can hold covered pixels: s.qcount[0] = first, s.qcount[1] = last + 1 (the caller keeps
     // them at H and 0 between steps)
