@@ -95,12 +95,13 @@ def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=100):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 2: 64)")
     ap.add_argument("--in-flight", type=int, default=8,
                     help="batches processed together (a 64-image solve launch occupies an eighth of the chip; eight batches "
                          "in flight fill the chip); every batch keeps its own loss normaliser")
+    ap.add_argument("--streams", type=int, default=2, help="launch streams the groups alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,21 +134,29 @@ def main():
     pre = maps.squeeze(1).contiguous()
     packed = getattr(maps, "_nemo_packed_grid", None) or ops.grid_pack(pre)   # one-off, like the grid itself
     B = args.batch
-    fm, gts = synthetic_images(mod, clutter, B, first_seed=rank * B, dev=dev)
     cam = mod.camera()
     G = max(1, args.in_flight)
     # G batches of B images are in flight together: their kernels are launched once over G*B images
     # (every batch keeps its own loss normaliser B), so that a 300-step solve launch has G*B workgroups
     # for the 256 CUs instead of B.
-    fm_g = fm.repeat(G, 1, 1, 1) if G > 1 else fm
-    table = torch.empty(ops.table_shape(mod.mesh, G * B, H * W), device=dev)
-    gathered = [torch.empty(G * B, 7, device=dev) for _ in range(world)] if world > 1 else None
+    parts = [synthetic_images(mod, clutter, B, first_seed=(rank * G + g) * B, dev=dev) for g in range(G)]   # G * B distinct images
+    fm_g = torch.cat([p_[0] for p_ in parts]) if G > 1 else parts[0][0]
+    gts = parts[0][1]
+    del parts
+    # Two launch streams, alternating groups: the front kernels of the next group (clutter, grid, table) fill the
+    # compute units that the workgroups of a solve launch leave as they finish at different times.
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    tables = [torch.empty(ops.table_shape(mod.mesh, G * B, H * W), device=dev) for _ in range(n_streams)]
+    gathered = [[torch.empty(G * B, 7, device=dev) for _ in range(world)] for _ in range(n_streams)] if world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}
 
-    def one_group(g, timed=False, host_out=None):
-        """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major)."""
+    def one_group(g, timed=False, host_out=None, slot=0):
+        """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major).
+        slot: which stream's buffers to use (the caller has made that stream current)."""
         n = g * B
+        table = tables[slot]
         x = fm_g[:n]
         if timed:
             ev[0].record()
@@ -174,8 +183,8 @@ def main():
                 dist.all_gather(part, res.cpu())
                 res = torch.cat(part).to(dev)
             elif g == G:
-                dist.all_gather(gathered, res)
-                res = torch.cat(gathered)
+                dist.all_gather(gathered[slot], res)
+                res = torch.cat(gathered[slot])
             else:
                 part = [torch.empty(n, 7, device=dev) for _ in range(world)]
                 dist.all_gather(part, res)
@@ -197,18 +206,21 @@ def main():
         if i > 0:
             for j, k in enumerate(list(kern_ms)):
                 kern_ms[k] += ev[j].elapsed_time(ev[j + 1]) / (n_probe - 1)
-    done = 0
+    done, k = 0, 0
     while done < args.warmup:
         g = min(G, args.warmup - done)
-        one_group(g)
+        with torch.cuda.stream(streams[k % n_streams]):
+            one_group(g, slot=k % n_streams)
         done += g
+        k += 1
     groups = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
     host_res = [torch.empty(world * g * B, 7).pin_memory() for g in groups]
     sync()
     # timed: exactly `steps` batches of B images per GPU, G at a time; every result is copied to the host
     t0 = time.perf_counter()
-    for g, out in zip(groups, host_res):
-        one_group(g, host_out=out)
+    for k, (g, out) in enumerate(zip(groups, host_res)):
+        with torch.cuda.stream(streams[k % n_streams]):
+            one_group(g, host_out=out, slot=k % n_streams)
     sync()
     elapsed = time.perf_counter() - t0
     res = host_res[0][:B]
@@ -245,7 +257,7 @@ def main():
                                    "80x100x128 feature maps, cuboid mesh V=1118 F=1904, 144-pose pre-rendered grid scoring + "
                                    "300 Adam steps per image, random-init vertex bank",
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": int(pre.shape[0]), "adam_steps": EPOCHS,
-                       "batches_in_flight": G,
+                       "batches_in_flight": G, "launch_streams": n_streams,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
