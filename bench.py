@@ -271,7 +271,7 @@ def main():
                                  "so frac > 1 means it beats the streaming roofline; see DESIGN.md"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mod, mem, clutter, v, f, fm[0], pre, cs, ths)
+            out["cpu_baseline"] = cpu_baseline(mod, mem, clutter, v, f, fm_g[0], pre, cs, ths)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
