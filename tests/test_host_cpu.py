@@ -328,3 +328,24 @@ def test_table_layout_round_trip():
     assert torch.equal(ops.table_dense(tab, 10, 300), dense)
     assert float(tab.sum()) == float(dense.sum())            # padding is zero
     assert float(tab[1, 2, 1, 300 % 128 - 1, 1]) == float(dense[1, 5, 299])
+
+
+def test_top_k_grid_poses_are_best_first_and_stable(monkeypatch):
+    """Host logic of the multi-hypothesis initialisation: the k lowest grid losses per image, ties in grid
+    order, column 0 = the arg-min pose (the device scoring is replaced by a fixed loss table)."""
+    from nemo_amd import batch_solve_pose as bsp
+    loss = torch.tensor([[0.5, 0.2, 0.9, 0.2, 0.1], [0.3, 0.3, 0.3, 0.8, 0.05]])
+    monkeypatch.setattr(bsp.ops, "grid_score",
+                        lambda pre, fm, clu, packed=None: (loss, loss.argmin(dim=1).int(), loss.min(dim=1)[0]))
+    pos = torch.arange(15, dtype=torch.float32).reshape(5, 3)
+    theta = torch.arange(5, dtype=torch.float32) * 0.1
+    maps = torch.zeros(5, 1, 2, 2, 2)
+    C1, t1, m1 = bsp.get_init_pos_rendered_dim0(maps, pos, theta, torch.zeros(2, 2, 2, 2))
+    assert torch.equal(C1, pos[[4, 4]]) and torch.equal(t1, theta[[4, 4]]) and torch.equal(m1, torch.tensor([0.1, 0.05]))
+    C3, t3, m3 = bsp.get_init_pos_rendered_dim0(maps, pos, theta, torch.zeros(2, 2, 2, 2), top_k=3)
+    assert C3.shape == (2, 3, 3) and t3.shape == (2, 3)
+    assert torch.equal(t3, theta[torch.tensor([[4, 1, 3], [4, 0, 1]])])
+    assert torch.equal(C3[:, 0], C1) and torch.equal(m3[:, 0], m1)
+    assert torch.equal(m3, torch.tensor([[0.1, 0.2, 0.2], [0.05, 0.3, 0.3]]))
+    with pytest.raises(ValueError):
+        bsp.get_init_pos_rendered_dim0(maps, pos, theta, torch.zeros(2, 2, 2, 2), top_k=6)
