@@ -64,6 +64,15 @@ __device__ inline void normalize3(float x, float y, float z, float* o, float* n_
     *n_out = n;
 }
 
+// The same with one reciprocal instead of three divisions (optimisation loop: a couple of ulp).
+__device__ inline void normalize3_fast(float x, float y, float z, float* o, float* n_out) {
+    float n = sqrtf((x * x + y * y) + z * z);
+    n = n > kNormEps ? n : (n != n ? n : kNormEps);
+    const float inv = __builtin_amdgcn_rcpf(n);
+    o[0] = x * inv; o[1] = y * inv; o[2] = z * inv;
+    *n_out = n;
+}
+
 __device__ inline void cross3(const float* a, const float* b, float* o) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
@@ -99,13 +108,13 @@ __device__ inline void pose_setup(const CamConst& cc, const float* C, float thet
                                   PoseCam* pc) {
     const float up[3] = {0.0f, 1.0f, 0.0f};
     float v[3] = {0.0f - C[0], 0.0f - C[1], 0.0f - C[2]};
-    normalize3(v[0], v[1], v[2], pc->az, &pc->nv);
+    if (EXACT) normalize3(v[0], v[1], v[2], pc->az, &pc->nv); else normalize3_fast(v[0], v[1], v[2], pc->az, &pc->nv);
     float w[3];
     cross3(up, pc->az, w);
-    normalize3(w[0], w[1], w[2], pc->ax, &pc->nw);
+    if (EXACT) normalize3(w[0], w[1], w[2], pc->ax, &pc->nw); else normalize3_fast(w[0], w[1], w[2], pc->ax, &pc->nw);
     float u[3];
     cross3(pc->az, pc->ax, u);
-    normalize3(u[0], u[1], u[2], pc->ay, &pc->nu);
+    if (EXACT) normalize3(u[0], u[1], u[2], pc->ay, &pc->nu); else normalize3_fast(u[0], u[1], u[2], pc->ay, &pc->nu);
     pc->degenerate = 0;
     if (fabsf(pc->ax[0]) <= 5e-3f && fabsf(pc->ax[1]) <= 5e-3f && fabsf(pc->ax[2]) <= 5e-3f) {
         float r[3], nr;
@@ -124,8 +133,8 @@ __device__ inline void pose_setup(const CamConst& cc, const float* C, float thet
     }
     for (int j = 0; j < 3; ++j)
         pc->T[j] = -((pc->R[0 + j] * C[0] + pc->R[3 + j] * C[1]) + pc->R[6 + j] * C[2]);
-    pc->bx = (cc.half_w - px) / cc.s;
-    pc->by = (cc.half_h - py) / cc.s;
+    if (EXACT) { pc->bx = (cc.half_w - px) / cc.s; pc->by = (cc.half_h - py) / cc.s; }
+    else { const float is = __builtin_amdgcn_rcpf(cc.s); pc->bx = (cc.half_w - px) * is; pc->by = (cc.half_h - py) * is; }
     pc->C[0] = C[0]; pc->C[1] = C[1]; pc->C[2] = C[2];
 }
 
@@ -408,7 +417,9 @@ __device__ inline float pixel_score(const float4& v0, const float4& v1, const fl
 }
 #pragma clang fp contract(off)
 
-// From the reduced sums to the gradient of (C[3], theta, px, py).
+// From the reduced sums to the gradient of (C[3], theta, px, py).  EXACT = false (optimisation loop): the
+// divisions by the three norms and by the NDC scale are reciprocals.
+template <bool EXACT = true>
 __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, const float* M, const float* S, float gbx,
                                      float gby, float* gC, float* gtheta, float* gpx, float* gpy) {
     // dL/dR = R (M - T^T (x) S),  dL/dT = S
@@ -426,6 +437,8 @@ __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, cons
             GR[i * 3 + j] += -pc.C[i] * S[j];
             gc[i] += -pc.R[i * 3 + j] * S[j];
         }
+    const float inu = EXACT ? 1.0f / pc.nu : __builtin_amdgcn_rcpf(pc.nu), inw = EXACT ? 1.0f / pc.nw : __builtin_amdgcn_rcpf(pc.nw),
+                inv_ = EXACT ? 1.0f / pc.nv : __builtin_amdgcn_rcpf(pc.nv), is = EXACT ? 1.0f / cc.s : __builtin_amdgcn_rcpf(cc.s);
     // R = R0 Rz(theta): R[i][0] = r0 c + r1 s, R[i][1] = r1 c - r0 s, R[i][2] = r2
     float gth = 0.f;
     float G0[9];   // dL/dR0, R0 = [ax ay az] as columns
@@ -442,7 +455,10 @@ __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, cons
     {
         float d = Gy[0] * pc.ay[0] + Gy[1] * pc.ay[1] + Gy[2] * pc.ay[2];
         float Gu[3];
-        for (int i = 0; i < 3; ++i) Gu[i] = (pc.nu > kNormEps ? (Gy[i] - pc.ay[i] * d) : Gy[i]) / pc.nu;
+        for (int i = 0; i < 3; ++i) {
+            const float t_ = pc.nu > kNormEps ? (Gy[i] - pc.ay[i] * d) : Gy[i];
+            Gu[i] = EXACT ? t_ / pc.nu : t_ * inu;
+        }
         float t1[3], t2[3];
         cross3(pc.ax, Gu, t1);   // dL/dz += x x Gu
         cross3(Gu, pc.az, t2);   // dL/dx += Gu x z
@@ -453,7 +469,10 @@ __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, cons
         const float up[3] = {0.f, 1.f, 0.f};
         float d = Gx[0] * pc.ax[0] + Gx[1] * pc.ax[1] + Gx[2] * pc.ax[2];
         float Gw[3];
-        for (int i = 0; i < 3; ++i) Gw[i] = (pc.nw > kNormEps ? (Gx[i] - pc.ax[i] * d) : Gx[i]) / pc.nw;
+        for (int i = 0; i < 3; ++i) {
+            const float t_ = pc.nw > kNormEps ? (Gx[i] - pc.ax[i] * d) : Gx[i];
+            Gw[i] = EXACT ? t_ / pc.nw : t_ * inw;
+        }
         float t[3];
         cross3(Gw, up, t);       // dL/dz += Gw x up
         for (int i = 0; i < 3; ++i) Gz[i] += t[i];
@@ -462,14 +481,15 @@ __device__ inline void pose_backward(const CamConst& cc, const PoseCam& pc, cons
     {
         float d = Gz[0] * pc.az[0] + Gz[1] * pc.az[1] + Gz[2] * pc.az[2];
         for (int i = 0; i < 3; ++i) {
-            float Gv = (pc.nv > kNormEps ? (Gz[i] - pc.az[i] * d) : Gz[i]) / pc.nv;
+            const float t_ = pc.nv > kNormEps ? (Gz[i] - pc.az[i] * d) : Gz[i];
+            const float Gv = EXACT ? t_ / pc.nv : t_ * inv_;
             gc[i] += -Gv;
         }
     }
     gC[0] = gc[0]; gC[1] = gc[1]; gC[2] = gc[2];
     *gtheta = gth;
-    *gpx = -gbx / cc.s;
-    *gpy = -gby / cc.s;
+    *gpx = EXACT ? -gbx / cc.s : -gbx * is;
+    *gpy = EXACT ? -gby / cc.s : -gby * is;
 }
 
 }  // namespace nemo

@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
             if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
             float g[6];
-            pose_backward(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
+            pose_backward<false>(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
             if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
 #pragma unroll
             for (int k = 0; k < 6; ++k) os->g[k] = g[k];
