@@ -1102,10 +1102,13 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         if (tid == 0) {
             // every thread has read the row range (a barrier ago): back to "no rows", first face task = number of waves
             if (!WARP) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u; }
-            float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
-            if (step == 0) os->first_loss = loss;
-            os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
-            if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
+            // the loss value is only reported (first step, last step, history): the update needs the gradient alone
+            if (step == 0 || last || a.out_hist) {
+                const float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
+                if (step == 0) os->first_loss = loss;
+                if (last) os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
+                if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
+            }
             float g[6];
             pose_backward<false>(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
             if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
