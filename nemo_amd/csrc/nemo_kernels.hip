@@ -828,8 +828,7 @@ extern "C" int nemo_vertex_similarity(nemo_mesh_t m, const float* table, const f
 #endif
 
 struct OptState {
-    float P[6], m[6], v[6], g[6];
-    double lr, b1p, b2p;
+    float P[6];                 // parameter values (mirror of the registers of wave 0)
     float first_loss, last_loss;
     float base_max, base_clu, box_max, box_clu, box_n;   // per-image constants of the loss (see solve_kernel)
 };
@@ -879,12 +878,10 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         s.qcount[0] = (unsigned)H; s.qcount[1] = 0u;       // row range of the covered pixels (see raster_direct)
         s.qcount[2] = kSolveThreads / 64;                  // next face task
         s.qcount[3] = 0u;                                  // length of the front-face list
-        for (int k = 0; k < 6; ++k) { os->m[k] = 0.0f; os->v[k] = 0.0f; }
         os->P[0] = a.init_campos[3 * h]; os->P[1] = a.init_campos[3 * h + 1]; os->P[2] = a.init_campos[3 * h + 2];
         os->P[3] = a.init_theta[h];
         os->P[4] = a.init_principal ? a.init_principal[2 * h] : (WARP ? 0.0f : a.def_px);
         os->P[5] = a.init_principal ? a.init_principal[2 * h + 1] : (WARP ? 0.0f : a.def_py);
-        os->lr = a.lr; os->b1p = 1.0; os->b2p = 1.0;
         os->first_loss = 0.0f; os->last_loss = 0.0f;
     }
     // per-image constants of the loss: sum_p max(0, clu) (what an uncovered image scores) and sum_p clu
@@ -916,6 +913,9 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         if (tid == 0) { os->box_max = s.tot[0]; os->box_clu = s.tot[1]; os->box_n = (float)(bw * bh); }
         __syncthreads();
     }
+    // Optimiser state in registers: lane k of wave 0 owns parameter k (value, first and second moment); the
+    // value is mirrored in os->P for the other readers (flow warp, final output).
+    float Pk = tid < 6 ? os->P[tid] : 0.0f, mom1 = 0.0f, mom2 = 0.0f;
     const float fHW = (float)HW;
     const unsigned int fmask = (1u << a.rc.face_bits) - 1u;
     (void)fmask;
@@ -934,20 +934,25 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 #endif
 
     for (int step = 0; step < a.steps; ++step) {
-        if (tid == 0) {
-            pose_setup<false>(a.rc.cc, os->P, os->P[3], WARP ? a.def_px : os->P[4], WARP ? a.def_py : os->P[5], s.pc);
-            // back faces may be skipped while the camera is outside the solid (outside its bounding box, with a margin)
-            bool outside = false;
+        if (tid < 64) {
+            float P[6];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float m = 1e-3f * (a.rc.aabb[3 + k] - a.rc.aabb[k]) + 1e-6f;
-                outside = outside || os->P[k] < a.rc.aabb[k] - m || os->P[k] > a.rc.aabb[3 + k] + m;
+            for (int k = 0; k < 6; ++k) P[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pk), k));
+            if (tid == 0) {
+                pose_setup<false>(a.rc.cc, P, P[3], WARP ? a.def_px : P[4], WARP ? a.def_py : P[5], s.pc);
+                // back faces may be skipped while the camera is outside the solid (outside its bounding box, with a margin)
+                bool outside = false;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float m = 1e-3f * (a.rc.aabb[3 + k] - a.rc.aabb[k]) + 1e-6f;
+                    outside = outside || P[k] < a.rc.aabb[k] - m || P[k] > a.rc.aabb[3 + k] + m;
+                }
+                s.pc->cull = a.rc.outward && outside;
+                // depth range of the keys: the vertices lie within the bounding radius of the mesh origin, whose view depth is T_z
+                const float z0 = s.pc->T[2] - a.rc.depth_margin;
+                s.pc->qz0 = z0;
+                s.pc->qc = 8388608.0f - z0 * a.rc.depth_scale;
             }
-            s.pc->cull = a.rc.outward && outside;
-            // depth range of the keys: the vertices lie within the bounding radius of the mesh origin, whose view depth is T_z
-            const float z0 = s.pc->T[2] - a.rc.depth_margin;
-            s.pc->qz0 = z0;
-            s.pc->qc = 8388608.0f - z0 * a.rc.depth_scale;
         }
         __syncthreads();
         STAMP(0);
@@ -1099,27 +1104,30 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         if (WARP)       // the key buffer was not consumed by a compaction: empty the rows that were drawn
             for (int p = row0 * W + tid; p < row1 * W; p += blockDim.x) s.zkey[p] = kEmptyKey32;
 
-        if (tid == 0) {
-            // every thread has read the row range (a barrier ago): back to "no rows", first face task = number of waves
-            if (!WARP) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u; }
-            // the loss value is only reported (first step, last step, history): the update needs the gradient alone
-            if (step == 0 || last || a.out_hist) {
-                const float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
-                if (step == 0) os->first_loss = loss;
-                if (last) os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
-                if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
-            }
-            float g[6];
-            pose_backward<false>(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
-            if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
-#pragma unroll
-            for (int k = 0; k < 6; ++k) os->g[k] = g[k];
-        }
-        // torch.optim.Adam (single-tensor path), one parameter per lane of wave 0: lerp for the first moment,
-        // mul + addcmul for the second, addcdiv.  LDS accesses of one wave complete in program order; the
-        // fence keeps the compiler from moving them.
+        // Wave 0: lane 0 turns the sums into the pose gradient, the six values are handed to lanes 0-5 through
+        // readlane, and each of those lanes makes torch.optim.Adam's update (single-tensor path: lerp for the
+        // first moment, mul + addcmul for the second, addcdiv) of its own parameter.
         if (tid < 64) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            float g[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (tid == 0) {
+                // every thread has read the row range (a barrier ago): back to "no rows", first face task = number of waves
+                if (!WARP) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u; }
+                // the loss value is only reported (first step, last step, history): the update needs the gradient alone
+                if (step == 0 || last || a.out_hist) {
+                    const float loss = 1.0f - ((os->base_max + s.tot[14]) / fHW - os->base_clu / fHW);
+                    if (step == 0) os->first_loss = loss;
+                    if (last) os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
+                    if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
+                }
+                pose_backward<false>(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
+                if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
+            }
+            float gk = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float t_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[k]), 0));
+                gk = tid == k ? t_ : gk;
+            }
             if (tid < np) {
                 float step_size, bc2s;
                 if (step < kSchedSteps) { const float2 sc = sched[step]; step_size = sc.x; bc2s = sc.y; }
@@ -1129,16 +1137,13 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     bc2s = (float)sqrt(1.0 - pow(a.beta2, (double)(step + 1)));
                 }
                 const float w1 = (float)(1.0 - a.beta1), b2f = (float)a.beta2, w2 = (float)(1.0 - a.beta2), epsf = (float)a.eps;
-                const float gk = os->g[tid];
-                float mk = os->m[tid], vk = os->v[tid];
-                const float diff = gk - mk;
-                mk = w1 < 0.5f ? mk + w1 * diff : gk - diff * (1.0f - w1);
-                vk = vk * b2f + (w2 * gk) * gk;
-                const float denom = sqrtf(vk) / bc2s + epsf;
-                os->P[tid] = os->P[tid] + step_size * (mk / denom);
-                os->m[tid] = mk; os->v[tid] = vk;
+                const float diff = gk - mom1;
+                mom1 = w1 < 0.5f ? mom1 + w1 * diff : gk - diff * (1.0f - w1);
+                mom2 = mom2 * b2f + (w2 * gk) * gk;
+                const float denom = sqrtf(mom2) / bc2s + epsf;
+                Pk = Pk + step_size * (mom1 / denom);
+                os->P[tid] = Pk;
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         STAMP(6);
         // the next iteration's first barrier orders these LDS accesses before s.tot / s.pc are reused
