@@ -935,6 +935,9 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 
     for (int step = 0; step < a.steps; ++step) {
         if (tid < 64) {
+            // serial section: seven waves of this hypothesis wait for it, so it goes ahead of the other
+            // hypothesis's waves on this SIMD
+            __builtin_amdgcn_s_setprio(3);
             float P[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) P[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pk), k));
@@ -953,6 +956,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                 s.pc->qz0 = z0;
                 s.pc->qc = 8388608.0f - z0 * a.rc.depth_scale;
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         STAMP(0);
@@ -1108,6 +1112,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         // readlane, and each of those lanes makes torch.optim.Adam's update (single-tensor path: lerp for the
         // first moment, mul + addcmul for the second, addcdiv) of its own parameter.
         if (tid < 64) {
+            __builtin_amdgcn_s_setprio(3);      // serial section again; the priority is dropped after the next pose set-up
             float g[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             if (tid == 0) {
                 // every thread has read the row range (a barrier ago): back to "no rows", first face task = number of waves
