@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=8,
                     help="batches processed together (a 64-image solve launch occupies an eighth of the chip; eight batches "
                          "in flight fill the chip); every batch keeps its own loss normaliser")
+    ap.add_argument("--hypotheses", type=int, default=1,
+                    help="initial poses per image (the K best grid poses; BASELINE configs[2] uses 8); 1 = configs[1]")
     ap.add_argument("--streams", type=int, default=2, help="launch streams the groups alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -145,6 +147,8 @@ def main():
     del parts
     # Two launch streams, alternating groups: the front kernels of the next group (clutter, grid, table) fill the
     # compute units that the workgroups of a solve launch leave as they finish at different times.
+    K_HYP = max(1, args.hypotheses)
+    hyp_image = torch.arange(G * B, device=dev, dtype=torch.int32).repeat_interleave(K_HYP)
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     tables = [torch.empty(ops.table_shape(mod.mesh, G * B, H * W), device=dev) for _ in range(n_streams)]
@@ -163,17 +167,24 @@ def main():
         clu = ops.clutter_score(x, clutter)
         if timed:
             ev[1].record()
-        _, idx, _ = ops.grid_score(pre, x, clu, packed=packed)
+        loss, idx, _ = ops.grid_score(pre, x, clu, packed=packed)
+        h2i = None
+        if K_HYP > 1:       # the K best grid poses of every image, best first (as solve_pose(..., hypotheses=K))
+            idx = torch.sort(loss, dim=1, stable=True)[1][:, :K_HYP].reshape(-1)
+            h2i = hyp_image[:n * K_HYP]
         idx = idx.long()
         if timed:
             ev[2].record()
         tab = ops.similarity_table(mod.mesh, x, out=table[:n])
         if timed:
             ev[3].record()
-        pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], global_batch=B * world, dof=3, steps=EPOCHS,
-                            lr=0.05, betas=(0.4, 0.6), lr_gamma=0.2, lr_every=EPOCHS // 3)
+        pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], hyp_to_image=h2i, global_batch=B * world, dof=3,
+                            steps=EPOCHS, lr=0.05, betas=(0.4, 0.6), lr_gamma=0.2, lr_every=EPOCHS // 3)
         if timed:
             ev[4].record()
+        if K_HYP > 1:       # keep the best-scoring hypothesis of every image
+            pose = pose.view(n, K_HYP, 8)
+            pose = pose[torch.arange(n, device=dev), pose[:, :, 6].argmin(dim=1)]
         sph = ops.spherical_angles(pose[:, 0:3])
         res = torch.cat([sph[:, 2:3], sph[:, 1:2], pose[:, 3:4], sph[:, 0:1], pose[:, 4:7]], dim=1)   # az, el, th, d, px, py, score
         if world > 1:
@@ -236,9 +247,9 @@ def main():
         errs = [pose_error(dict(azimuth=float(gts["azimuth"][i]), elevation=float(gts["elevation"][i]), theta=float(gts["theta"][i])),
                            dict(azimuth=float(host[i, 0]), elevation=float(host[i, 1]), theta=float(host[i, 2]))) for i in range(B)]
         med_err = sorted(errs)[len(errs) // 2] * 180 / math.pi
-        n_hyp_steps = args.steps * B * world * EPOCHS
+        n_hyp_steps = args.steps * B * world * EPOCHS * K_HYP
         solve_ms = kern_ms["solve"]
-        achieved = G * B * EPOCHS * ALGO_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9
+        achieved = G * B * K_HYP * EPOCHS * ALGO_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9
         # HBM-side traffic of the same launch shape, from the committed rocprofv3 --pmc passes (bench.py cannot
         # run the profiler on itself); None when the launch shape differs from the profiled one.
         traffic = None
@@ -246,7 +257,7 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
-            if tj.get("hypotheses_per_launch") == G * B and tj.get("adam_steps") == EPOCHS:
+            if tj.get("hypotheses_per_launch") == G * B * K_HYP and tj.get("adam_steps") == EPOCHS:
                 traffic = (tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
@@ -257,13 +268,13 @@ def main():
                                    "80x100x128 feature maps, cuboid mesh V=1118 F=1904, 144-pose pre-rendered grid scoring + "
                                    "300 Adam steps per image, random-init vertex bank",
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": int(pre.shape[0]), "adam_steps": EPOCHS,
-                       "batches_in_flight": G, "launch_streams": n_streams,
+                       "batches_in_flight": G, "launch_streams": n_streams, "hypotheses_per_image": K_HYP,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
-            "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B,
+            "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B * K_HYP,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
             "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": G * B * EPOCHS * ALGO_BYTES_PER_HYP_STEP,
+                         "algorithmic_bytes_per_launch": G * B * K_HYP * EPOCHS * ALGO_BYTES_PER_HYP_STEP,
                          "traffic_source": "profiles/r1_solve_traffic_v4.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
                          "note": "achieved = 300 steps x hypotheses per launch x 4.128 MB (one read of the image's feature map + clutter "
                                  "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
