@@ -207,30 +207,6 @@ __device__ inline void eval_and_min(int face, const FaceVerts& f, int p, float x
     atomicMin(&zbuf[p], depth_key(pz, face));
 }
 
-// Coverage test and depth-buffer update for the optimisation loop, all three depths positive.  Same
-// decision and the same depth as eval_and_min up to a few ulp (reciprocal instead of division,
-// contracted multiply-adds, the common factor 1/area dropped), at a fifth of the instructions: with
-// u_i = e_i * z_j * z_k the corrected barycentrics are u_i / sum(u), the pixel is inside when the three
-// edge functions share a sign, and the depth is z0 z1 z2 (e0 + e1 + e2) / sum(u).  Only the images
-// rendered for callers need the bit-exact rule; here a pixel centre within rounding distance of an
-// edge may fall on either side.
-#pragma clang fp contract(fast)
-__device__ inline void eval_and_min_fast(int face, const FaceVerts& f, int p, float xf, float yf, unsigned long long* zbuf) {
-    const float dx0 = xf - f.x0, dy0 = yf - f.y0, dx1 = xf - f.x1, dy1 = yf - f.y1, dx2 = xf - f.x2, dy2 = yf - f.y2;
-    const float e0 = dx1 * (f.y2 - f.y1) - dy1 * (f.x2 - f.x1);
-    const float e1 = dx2 * (f.y0 - f.y2) - dy2 * (f.x0 - f.x2);
-    const float e2 = dx0 * (f.y1 - f.y0) - dy0 * (f.x1 - f.x0);
-    const bool pos = e0 > 0.0f && e1 > 0.0f && e2 > 0.0f;
-    const bool neg = e0 < 0.0f && e1 < 0.0f && e2 < 0.0f;
-    if (!(pos || neg)) return;
-    const float z12 = f.z1 * f.z2;
-    const float su = e0 * z12 + f.z0 * (e1 * f.z2 + e2 * f.z1);
-    const float pz = (f.z0 * z12) * ((e0 + e1) + e2) * __builtin_amdgcn_rcpf(su);
-    if (!(pz >= 0.0f)) return;
-    atomicMin(&zbuf[p], depth_key(pz, face));
-}
-#pragma clang fp contract(off)
-
 // ------------------------------------------------------------------------------------------
 // Backward.  Per covered pixel the gradient of the loss w.r.t. the three barycentrics (gb) is
 // pushed through the perspective correction and the edge functions to the NDC position and depth
@@ -304,67 +280,8 @@ __device__ inline void pixel_backward(const CamConst& cc, const FaceVerts& f, co
     }
 }
 
-// Forward + backward of one covered pixel for the optimisation loop (values only need the loss
-// tolerance, not bit parity: reciprocals are the 1-ulp hardware form and fma contraction is allowed).
-// d[3]: similarity of the face's three vertices with the image feature at this pixel.
-// Returns obj = sum_i b_i d_i; if gscale != 0 accumulates the pose-gradient sums for dL/dobj = gscale.
-#pragma clang fp contract(fast)
-__device__ inline float pixel_score_and_grad(const CamConst& cc, const FaceVerts& f, const float* Xv0, const float* Xv1,
-                                             const float* Xv2, float xf, float yf, const float* d, float cl,
-                                             float inv_norm, PixelGrad* acc) {
-    float area = edge_fn(f.x2, f.y2, f.x0, f.y0, f.x1, f.y1) + kEps;
-    float inv_area = __builtin_amdgcn_rcpf(area);
-    float e0 = edge_fn(xf, yf, f.x1, f.y1, f.x2, f.y2);
-    float e1 = edge_fn(xf, yf, f.x2, f.y2, f.x0, f.y0);
-    float e2 = edge_fn(xf, yf, f.x0, f.y0, f.x1, f.y1);
-    float w0 = e0 * inv_area, w1 = e1 * inv_area, w2 = e2 * inv_area;
-    float t0 = w0 * f.z1 * f.z2, t1 = f.z0 * w1 * f.z2, t2 = f.z0 * f.z1 * w2;
-    float den_raw = (t0 + t1) + t2;
-    bool clamped = !(den_raw > kEps);
-    float den = clamped ? kEps : den_raw;
-    float inv_den = __builtin_amdgcn_rcpf(den);
-    float b0 = t0 * inv_den, b1 = t1 * inv_den, b2 = t2 * inv_den;
-    float obj = (b0 * d[0] + b1 * d[1]) + b2 * d[2];
-    float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
-    if (mk == 0.0f) return obj;
-    float g = -mk * inv_norm;
-    float gb0 = g * d[0], gb1 = g * d[1], gb2 = g * d[2];
-    float dot = gb0 * b0 + gb1 * b1 + gb2 * b2;
-    float gden = clamped ? 0.0f : -dot * inv_den;
-    float gt0 = gb0 * inv_den + gden, gt1 = gb1 * inv_den + gden, gt2 = gb2 * inv_den + gden;
-    float gw0 = gt0 * f.z1 * f.z2, gw1 = gt1 * f.z0 * f.z2, gw2 = gt2 * f.z0 * f.z1;
-    float gz0 = gt1 * w1 * f.z2 + gt2 * f.z1 * w2;
-    float gz1 = gt0 * w0 * f.z2 + gt2 * f.z0 * w2;
-    float gz2 = gt0 * w0 * f.z1 + gt1 * f.z0 * w1;
-    float ge0 = gw0 * inv_area, ge1 = gw1 * inv_area, ge2 = gw2 * inv_area;
-    float garea = -(gw0 * w0 + gw1 * w1 + gw2 * w2) * inv_area;
-    float gx0 = ge1 * -(yf - f.y2) + ge2 * (yf - f.y1) + garea * (f.y2 - f.y1);
-    float gy0 = ge1 * (xf - f.x2) + ge2 * (f.x1 - xf) + garea * (f.x1 - f.x2);
-    float gx1 = ge0 * (yf - f.y2) + ge2 * -(yf - f.y0) + garea * -(f.y2 - f.y0);
-    float gy1 = ge0 * (f.x2 - xf) + ge2 * (xf - f.x0) + garea * (f.x2 - f.x0);
-    float gx2 = ge0 * -(yf - f.y1) + ge1 * (yf - f.y0) + garea * (f.y1 - f.y0);
-    float gy2 = ge0 * (xf - f.x1) + ge1 * (f.x0 - xf) + garea * -(f.x1 - f.x0);
-    const float* Xs[3] = {Xv0, Xv1, Xv2};
-    float gxs[3] = {gx0, gx1, gx2}, gys[3] = {gy0, gy1, gy2}, gzs[3] = {gz0, gz1, gz2};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float* X = Xs[i];
-        float iz = __builtin_amdgcn_rcpf(X[2]);
-        float gX = gxs[i] * cc.a * iz;
-        float gY = gys[i] * cc.a * iz;
-        float gZ = gzs[i] - (gX * X[0] + gY * X[1]) * iz;
-        acc->M[0] += X[0] * gX; acc->M[1] += X[0] * gY; acc->M[2] += X[0] * gZ;
-        acc->M[3] += X[1] * gX; acc->M[4] += X[1] * gY; acc->M[5] += X[1] * gZ;
-        acc->M[6] += X[2] * gX; acc->M[7] += X[2] * gY; acc->M[8] += X[2] * gZ;
-        acc->S[0] += gX; acc->S[1] += gY; acc->S[2] += gZ;
-        acc->gbx += gxs[i];
-        acc->gby += gys[i];
-    }
-    return obj;
-}
-#pragma clang fp contract(off)
-
-// The same forward + backward for the optimisation loop, straight-line and in fewer operations.
+// Forward + backward of one covered pixel for the optimisation loop, straight-line (values only need the
+// loss tolerance, not bit parity: reciprocals are the 1-ulp hardware form and fma contraction is allowed).
 // v_i = (x_ndc, y_ndc, Z, 1/Z) of the face's vertices, all in front of the camera.  With pixel-relative
 // vectors (dx_i, dy_i) = pixel - v_i the edge functions are cross products, e0 = dy1 dx2 - dx1 dy2 ...;
 // u_i = e_i z_j z_k, b_i = u_i / sum(u) (the 1/area factor cancels and is never formed),

@@ -25,8 +25,9 @@
 //                      arithmetic of geom.h, so the result equals a serial scan over the faces.
 //
 // Rasteriser of the optimisation loop (no image leaves the kernel):
-//   raster_direct      faces are handed out in tasks of 64 from an LDS counter; a lane orients its face's
-//                      edge functions, skips it when it looks away from a camera outside a closed solid,
+//   raster_direct      when faces that look away can be skipped (closed solid, camera outside) the ones that
+//                      look at the camera are listed first; faces are then handed out in tasks of 64 from
+//                      an LDS counter; a lane orients its face's edge functions
 //                      and walks the pixel centres of its bounding box with incrementally stepped edge
 //                      functions and depth; 32-bit atomic min on (quantised depth << face bits | face).  No
 //                      queue, no second pass; the covered entries are compacted in place (compact_covered32).
@@ -402,22 +403,17 @@ __device__ inline int wave_inclusive_scan(int v, int* total) {
     return v;
 }
 
-// Coverage test of one (face, pixel) pair and depth-buffer update.  EXACT: the reference's arithmetic
-// bit for bit; otherwise the short form for faces in front of the camera (others take the exact path).
+// Coverage test of one (face, pixel) pair and depth-buffer update in the reference's arithmetic, bit for bit.
+// (EXACT is always true: the optimisation loop has its own rasteriser, raster_direct.)
 template <bool EXACT>
 __device__ inline void eval_pair(int face, const FaceVerts& fv, int xi, int yi, int W, const Lds& s) {
+    static_assert(EXACT, "the queue rasteriser only exists in its exact form");
     const float xf = s.xs[xi], yf = s.ys[yi];
-    if (!EXACT && fv.z0 > 0.0f && fv.z1 > 0.0f && fv.z2 > 0.0f) {
-        eval_and_min_fast(face, fv, yi * W + xi, xf, yf, s.zbuf);
-        return;
-    }
     const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
     const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
     if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) return;     // exact bounding-box rejection
     eval_and_min(face, fv, yi * W + xi, xf, yf, s.zbuf);
 }
-
-constexpr int kInPlace = 6;
 
 // Key buffer must be empty and s.qcount[0..1] == 0 on entry; ends with a barrier.
 template <bool FACES_LDS, bool EXACT>
@@ -510,26 +506,6 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
                     for (int jx = jx0; jx < jx0 + nx; ++jx) eval_pair<EXACT>(f, fv, W - 1 - jx, H - 1 - jy, W, s);
             }
         }
-        if (!EXACT) {
-            // The first kInPlace candidates of every face are evaluated right here, while the face is in
-            // registers (short form, pixel centres from the affine approximation); what is left of a
-            // larger face goes through the queue.  The loop ends as soon as no lane of the wave has a
-            // candidate left.
-            const bool inplace = zpos;
-            for (int it = 0; it < kInPlace; ++it) {
-                const bool has = inplace && (mask_lo | mask_hi) != 0u;
-                if (!__any(has)) break;
-                if (has) {
-                    const bool lo_half = mask_lo != 0u;
-                    const unsigned int m = lo_half ? mask_lo : mask_hi;
-                    const int k = __ffs((int)m) - 1;
-                    if (lo_half) mask_lo = m & (m - 1); else mask_hi = m & (m - 1);
-                    const int jx = jx0 + (k & 7), jy = jy0 + (k >> 3) + (lo_half ? 0 : 4);
-                    const float xf = __builtin_fmaf((float)jx, dx, x_org), yf = __builtin_fmaf((float)jy, dy, y_org);
-                    eval_and_min_fast(f, fv, (H - 1 - jy) * W + (W - 1 - jx), xf, yf, s.zbuf);
-                }
-            }
-        }
         {
             const int n = __popc(mask_lo) + __popc(mask_hi);
             cnt_near = near ? n : 0;
@@ -537,7 +513,7 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
         }
         P1STAMP(1);
         int total = 0, incl = 0;
-        if (EXACT || __any((cnt_near | cnt_far) != 0)) incl = wave_inclusive_scan(cnt_near | (cnt_far << 16), &total);
+        incl = wave_inclusive_scan(cnt_near | (cnt_far << 16), &total);
         if (total) {
             unsigned int bn = 0, bf = 0;
             if ((threadIdx.x & 63) == 0) {
