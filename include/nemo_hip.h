@@ -218,6 +218,43 @@ int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */
 int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream);
 
+/* ---- feature-bank bookkeeping of multi-object batches (the reference's CuNeMo extension) ----
+ * An image n holds up to M objects: sample_indexs[n,i] = mesh index of object i (-1: none); its K padded
+ * vertex slots are the objects' vertices back to back, object i starting at slot sample_shifts[n,i];
+ * input_valid[n] = slots in use.  The bank holds the L meshes back to back, mesh l starting at
+ * bank_shifts[l]; KK = bank rows.  All index arrays i32, device memory.
+ *
+ * nemo_gather_features replaces _C.gather_features (cu_layers/CuNeMo/csrc/gather_features/
+ * gather_features.cu:24-68,101-150, bound in csrc/ext.cpp):
+ *   forward_mapping[n,k] = bank row of slot (n,k), -1 for k >= input_valid[n];
+ *   out_feat[v,:] = sum over the slots mapped to v of weight[n,k] * feat[n,k,:];  out_weight[v] = sum of the
+ *   weights.  Every output element is written (no zero-fill needed).  The sums run in a fixed order
+ *   (image, then object) instead of the reference's atomicAdd order.  Precondition as in the reference's
+ *   wrapper (gather_features.py:26-30): sample_shifts are the running sums of the objects' vertex counts. */
+int nemo_gather_features(const float* feat, const float* weight, const int32_t* input_valid,
+                         const int32_t* bank_shifts, const int32_t* sample_shifts, const int32_t* sample_indexs,
+                         int32_t N, int32_t M, int32_t K, int32_t C, int32_t L, int32_t KK, float* out_feat,
+                         float* out_weight, int32_t* forward_mapping, void* stream);
+/* _C.gather_features_backward (gather_features.cu:71-98,153-190): per slot
+ *   gi_weight[n,k] = g_weight[v] + <g_feat[v,:], feat[n,k,:]>,  gi_feat[n,k,:] = weight[n,k] * g_feat[v,:],
+ * zeros for padding slots; every output element is written. */
+int nemo_gather_features_backward(const float* g_feat, const float* g_weight, const float* feat,
+                                  const float* weight, const int32_t* forward_mapping, int32_t N, int32_t K,
+                                  int32_t C, float* gi_feat, float* gi_weight, void* stream);
+/* _C.gather_idx (csrc/mask_weight/mask_weight.cu:10-56,93-135): per slot the object's mesh index, the
+ * vertex index inside that mesh, the mesh's first bank row (bank_starts[mesh]) and its vertex count
+ * (sample_n_verts[n,i]); zeros for padding slots.  Outputs [N,K] i32. */
+int nemo_gather_idx(const int32_t* input_valid, const int32_t* sample_shifts, const int32_t* sample_indexs,
+                    const int32_t* sample_n_verts, const int32_t* bank_starts, int32_t N, int32_t M, int32_t K,
+                    int32_t* object_idx, int32_t* source_vert_idx, int32_t* verts_start, int32_t* num_verts,
+                    void* stream);
+/* _C.mask_weight (mask_weight.cu:59-90,139-177): out[s,k] for selected slot s and bank column k (K columns)
+ *   = verts_dist_weight[object_idx[s], source_vert_idx[s], k - verts_start[s]]  for verts_start[s] <= k < verts_end[s],
+ *   = weight_c for k >= clutter_start, = weight_x otherwise.  verts_dist_weight [n_obj,V,V] f32. */
+int nemo_mask_weight(const int32_t* object_idx, const int32_t* source_vert_idx, const int32_t* verts_start,
+                     const int32_t* verts_end, const float* verts_dist_weight, float weight_x, float weight_c,
+                     int32_t clutter_start, int32_t S, int32_t K, int32_t V, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,10 +6,11 @@ this package is the host-side mirror of the reference interface for that path.
 from . import ops
 from .batch_solve_pose import get_pre_render_samples, solve_pose
 from .cameras import MeshRasterizer, PerspectiveCameras, RasterizationSettings
-from .feature_banks import FeatureBankNeMo
+from . import cu_nemo
+from .feature_banks import FeatureBankNeMo, MaskCreater
 from .mesh_interpolate_module import MeshInterpolateModule
 from .nemo import NeMo, classify_by_render_compare
 from . import solve_pose_keypoint
 
 __all__ = ["ops", "get_pre_render_samples", "solve_pose", "MeshRasterizer", "PerspectiveCameras",
-           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "NeMo", "classify_by_render_compare", "solve_pose_keypoint"]
+           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "MaskCreater", "cu_nemo", "NeMo", "classify_by_render_compare", "solve_pose_keypoint"]

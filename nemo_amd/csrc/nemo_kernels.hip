@@ -154,6 +154,19 @@ __device__ inline int table_offset(int vg_n, int v, int p) {          // within 
 }
 
 namespace nemo {
+void launch_slot_map(const int32_t* input_valid, const int32_t* bank_shifts, const int32_t* sample_shifts, const int32_t* sample_indexs,
+                     int N, int M, int K, int32_t* forward_mapping, hipStream_t st);
+void launch_gather_features(const float* feat, const float* weight, const int32_t* bank_shifts, const int32_t* sample_shifts,
+                            const int32_t* sample_indexs, const int32_t* forward_mapping, int N, int M, int K, int C, int L, int KK,
+                            float* out_feat, float* out_weight, hipStream_t st);
+void launch_gather_features_backward(const float* g_feat, const float* g_weight, const float* feat, const float* weight,
+                                     const int32_t* forward_mapping, int NK, int C, float* gi_feat, float* gi_weight, hipStream_t st);
+void launch_gather_idx(const int32_t* input_valid, const int32_t* sample_shifts, const int32_t* sample_indexs,
+                       const int32_t* sample_n_verts, const int32_t* bank_starts, int N, int M, int K, int32_t* object_idx,
+                       int32_t* source_vert_idx, int32_t* verts_start, int32_t* num_verts, hipStream_t st);
+void launch_mask_weight(const int32_t* object_idx, const int32_t* source_vert_idx, const int32_t* verts_start, const int32_t* verts_end,
+                        const float* verts_dist_weight, float weight_x, float weight_c, int clutter_start, int S, int K, int V,
+                        float* out, hipStream_t st);
 bool split_table_supported(int C);
 size_t split_bank_bytes(int V, int C);
 void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_t st);
@@ -1328,6 +1341,67 @@ extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B
                                 : nemo::launch_table_gemm(m->memory_t, feat, table, m->V, m->C, HW, B, (hipStream_t)stream);
     if (rc)
         return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table: too many tiles for one launch");
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// feature-bank bookkeeping of multi-object batches (kernels in bank_ops.hip)
+// ------------------------------------------------------------------------------------------
+extern "C" int nemo_gather_features(const float* feat, const float* weight, const int32_t* input_valid, const int32_t* bank_shifts,
+                                    const int32_t* sample_shifts, const int32_t* sample_indexs, int32_t N, int32_t M, int32_t K,
+                                    int32_t C, int32_t L, int32_t KK, float* out_feat, float* out_weight,
+                                    int32_t* forward_mapping, void* stream) {
+    if (N < 0 || M <= 0 || K < 0 || C <= 0 || L <= 0 || KK < 0) return fail(NEMO_ERR_INVALID, "nemo_gather_features: bad size");
+    if ((long long)N * K > 0x7FFFFFFFLL) return fail(NEMO_ERR_UNSUPPORTED, "nemo_gather_features: N * K too large");
+    if (!bank_shifts || !sample_shifts || !sample_indexs || (KK > 0 && (!out_feat || !out_weight)) ||
+        (N * K > 0 && (!feat || !weight || !input_valid || !forward_mapping)))
+        return fail(NEMO_ERR_INVALID, "nemo_gather_features: null argument");
+    if (N * K > 0) nemo::launch_slot_map(input_valid, bank_shifts, sample_shifts, sample_indexs, N, M, K, forward_mapping, (hipStream_t)stream);
+    if (KK > 0)
+        nemo::launch_gather_features(feat, weight, bank_shifts, sample_shifts, sample_indexs, forward_mapping, N, M, K, C, L, KK, out_feat,
+                                     out_weight, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" int nemo_gather_features_backward(const float* g_feat, const float* g_weight, const float* feat, const float* weight,
+                                             const int32_t* forward_mapping, int32_t N, int32_t K, int32_t C, float* gi_feat,
+                                             float* gi_weight, void* stream) {
+    if (N < 0 || K < 0 || C <= 0) return fail(NEMO_ERR_INVALID, "nemo_gather_features_backward: bad size");
+    if ((long long)N * K > 0x7FFFFFFFLL) return fail(NEMO_ERR_UNSUPPORTED, "nemo_gather_features_backward: N * K too large");
+    if (N * K == 0) return NEMO_OK;
+    if (!g_feat || !g_weight || !feat || !weight || !forward_mapping || !gi_feat || !gi_weight)
+        return fail(NEMO_ERR_INVALID, "nemo_gather_features_backward: null argument");
+    nemo::launch_gather_features_backward(g_feat, g_weight, feat, weight, forward_mapping, N * K, C, gi_feat, gi_weight, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" int nemo_gather_idx(const int32_t* input_valid, const int32_t* sample_shifts, const int32_t* sample_indexs,
+                               const int32_t* sample_n_verts, const int32_t* bank_starts, int32_t N, int32_t M, int32_t K,
+                               int32_t* object_idx, int32_t* source_vert_idx, int32_t* verts_start, int32_t* num_verts, void* stream) {
+    if (N < 0 || M <= 0 || K < 0) return fail(NEMO_ERR_INVALID, "nemo_gather_idx: bad size");
+    if ((long long)N * K > 0x7FFFFFFFLL) return fail(NEMO_ERR_UNSUPPORTED, "nemo_gather_idx: N * K too large");
+    if (N * K == 0) return NEMO_OK;
+    if (!input_valid || !sample_shifts || !sample_indexs || !sample_n_verts || !bank_starts || !object_idx || !source_vert_idx ||
+        !verts_start || !num_verts)
+        return fail(NEMO_ERR_INVALID, "nemo_gather_idx: null argument");
+    nemo::launch_gather_idx(input_valid, sample_shifts, sample_indexs, sample_n_verts, bank_starts, N, M, K, object_idx, source_vert_idx,
+                            verts_start, num_verts, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" int nemo_mask_weight(const int32_t* object_idx, const int32_t* source_vert_idx, const int32_t* verts_start,
+                                const int32_t* verts_end, const float* verts_dist_weight, float weight_x, float weight_c,
+                                int32_t clutter_start, int32_t S, int32_t K, int32_t V, float* out, void* stream) {
+    if (S < 0 || K < 0 || V <= 0) return fail(NEMO_ERR_INVALID, "nemo_mask_weight: bad size");
+    if (S == 0 || K == 0) return NEMO_OK;
+    if (!object_idx || !source_vert_idx || !verts_start || !verts_end || !verts_dist_weight || !out)
+        return fail(NEMO_ERR_INVALID, "nemo_mask_weight: null argument");
+    nemo::launch_mask_weight(object_idx, source_vert_idx, verts_start, verts_end, verts_dist_weight, weight_x, weight_c, clutter_start, S,
+                             K, V, out, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }
