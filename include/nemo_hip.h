@@ -218,6 +218,16 @@ int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */
 int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream);
 
+/* Training-side keypoint annotation, get_one_standard of nemo/models/project_kp.py:175-247 for one mesh per
+ * pose (PackedRaster, mesh_mode 'single', type 'near', :132-143): per pose the mesh vertices projected to
+ * feature-map pixels, out_kp [n,V,2] = (y, x) (clamped to the map when restrict_to_boundary != 0), and
+ * out_vis [n,V] u8 = 1 where the distance map (per-vertex distance to cam_loc = -inverse(R) T, interpolated
+ * over the rasterised faces) read at the nearest pixel equals the vertex's own distance within dist_thr.
+ * principal [n,2] in feature-map pixels or NULL.  The distance map is never materialised. */
+int nemo_project_keypoints(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
+                           const float* principal, int32_t n, float dist_thr, int32_t restrict_to_boundary,
+                           float* out_kp, uint8_t* out_vis, void* stream);
+
 /* ---- feature-bank bookkeeping of multi-object batches (the reference's CuNeMo extension) ----
  * An image n holds up to M objects: sample_indexs[n,i] = mesh index of object i (-1: none); its K padded
  * vertex slots are the objects' vertices back to back, object i starting at slot sample_shifts[n,i];

@@ -11,6 +11,7 @@ from .feature_banks import FeatureBankNeMo, MaskCreater
 from .mesh_interpolate_module import MeshInterpolateModule
 from .nemo import NeMo, classify_by_render_compare
 from . import solve_pose_keypoint
+from .project_kp import PackedRaster
 
 __all__ = ["ops", "get_pre_render_samples", "solve_pose", "MeshRasterizer", "PerspectiveCameras",
-           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "MaskCreater", "cu_nemo", "NeMo", "classify_by_render_compare", "solve_pose_keypoint"]
+           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "MaskCreater", "cu_nemo", "NeMo", "classify_by_render_compare", "solve_pose_keypoint", "PackedRaster"]

@@ -19,7 +19,7 @@ SYMBOLS = [
     "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_pack_bytes", "nemo_grid_pack",
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
     "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
-    "nemo_gather_features", "nemo_gather_features_backward", "nemo_gather_idx", "nemo_mask_weight",
+    "nemo_project_keypoints", "nemo_gather_features", "nemo_gather_features_backward", "nemo_gather_idx", "nemo_mask_weight",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
                                     C.POINTER(NemoAdam), f32p, f32p, vp]
     lib.nemo_align_maps.argtypes = [f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, vp]
     lib.nemo_spherical_angles.argtypes = [f32p, i32, f32p, vp]
+    lib.nemo_project_keypoints.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, C.c_float, i32, f32p, vp, vp]
     lib.nemo_gather_features.argtypes = [f32p, f32p, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32p, f32p, vp, vp]
     lib.nemo_gather_features_backward.argtypes = [f32p, f32p, f32p, f32p, vp, i32, i32, i32, f32p, f32p, vp]
     lib.nemo_gather_idx.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -1346,6 +1346,114 @@ extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B
 }
 
 // ------------------------------------------------------------------------------------------
+// training-side keypoint annotation: projected vertices + visibility (project_kp.py:175-247)
+// ------------------------------------------------------------------------------------------
+// get_one_standard for one mesh per pose: every vertex is projected to feature-map pixels (y, x), the mesh is
+// rasterised, the "distance" map (per-vertex distance to cam_loc, interpolated with the barycentrics) is read
+// at the pixel nearest to the projected vertex, and the vertex is visible when that value equals its own
+// distance within dist_thr.  Here the map never exists: after the bit-exact rasteriser has filled the key
+// buffer in LDS, each vertex looks up its one pixel, recomputes that pixel's barycentrics and interpolates the
+// three distances.  cam_loc follows the reference's formula -inverse(R) T (with the orthonormal R, -R^T T);
+// it is the camera centre only for symmetric R, and the test is self-consistent either way because map and
+// vertex use the same point.
+struct KeypointVisArgs {
+    RasterCtx rc;
+    const float* campos; const float* theta; const float* principal;
+    float def_px, def_py, focal, dist_thr;
+    int clamp_to_image;
+    float* out_kp; uint8_t* out_vis;
+};
+
+__device__ inline float kp_distance(const float* cl, float x, float y, float z) {
+    const float dx = cl[0] - x, dy = cl[1] - y, dz = cl[2] - z;
+    return sqrtf((dx * dx + dy * dy) + dz * dz);
+}
+
+template <bool FL>
+__global__ __launch_bounds__(kRasterThreads) void keypoint_vis_kernel(KeypointVisArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds s = carve(smem, a.rc.L);
+    const int n = blockIdx.x;
+    const int H = a.rc.cc.H, W = a.rc.cc.W, V = a.rc.V;
+    raster_prologue(a.rc, s);
+    const float px = a.principal ? a.principal[2 * n] : a.def_px, py = a.principal ? a.principal[2 * n + 1] : a.def_py;
+    if (threadIdx.x == 0) {
+        float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
+        pose_setup(a.rc.cc, C, a.theta[n], px, py, s.pc);
+    }
+    __syncthreads();
+    project_vertices(a.rc, s);
+    raster_faces<FL, true>(a.rc, s);
+    float R[9], T[3], cl[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = s.pc->R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[i] = s.pc->T[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cl[i] = -((R[i] * T[0] + R[3 + i] * T[1]) + R[6 + i] * T[2]);      // -(R^T T)_i
+    const float fW = (float)W, fH = (float)H;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const float X0 = a.rc.verts[3 * v], X1 = a.rc.verts[3 * v + 1], X2 = a.rc.verts[3 * v + 2];
+        float Xv[3], xn, yn;
+        project_vertex(a.rc.cc, R, T, s.pc->bx, s.pc->by, X0, X1, X2, Xv, &xn, &yn);
+        // screen point of the pinhole (f X + p Z) / Z, mirrored about the principal point (project_kp.py:186-188)
+        float x = 2.0f * px - (a.focal * Xv[0] + px * Xv[2]) / Xv[2];
+        float y = 2.0f * py - (a.focal * Xv[1] + py * Xv[2]) / Xv[2];
+        if (a.clamp_to_image) {
+            x = fmaxf(fminf(x, fW - 1.0f), 0.0f);
+            y = fmaxf(fminf(y, fH - 1.0f), 0.0f);
+        }
+        a.out_kp[((size_t)n * V + v) * 2] = y;
+        a.out_kp[((size_t)n * V + v) * 2 + 1] = x;
+        // grid_sample(mode='nearest', align_corners=False) at grid = p / size * 2 - 1: pixel index rint(((g + 1) size - 1) / 2)
+        const float gx = x / fW * 2.0f - 1.0f, gy = y / fH * 2.0f - 1.0f;
+        const float fx = rintf(((gx + 1.0f) * fW - 1.0f) / 2.0f), fy = rintf(((gy + 1.0f) * fH - 1.0f) / 2.0f);
+        float sampled = 0.0f;                                   // zero padding outside the map, 0 on the background
+        if (fx >= 0.0f && fx <= fW - 1.0f && fy >= 0.0f && fy <= fH - 1.0f) {
+            const int xi = (int)fx, yi = (int)fy;
+            const unsigned long long key = s.zbuf[yi * W + xi];
+            if (key != kEmptyKey) {
+                int i0, i1, i2;
+                load_face<FL>(a.rc, s, (int)(key & 0xFFFFFFFFull), &i0, &i1, &i2);
+                const FaceVerts fv = face_verts(s, i0, i1, i2);
+                float b[3], pz;
+                face_eval(fv, s.xs[xi], s.ys[yi], b, &pz);
+                const float d0 = kp_distance(cl, a.rc.verts[3 * i0], a.rc.verts[3 * i0 + 1], a.rc.verts[3 * i0 + 2]);
+                const float d1 = kp_distance(cl, a.rc.verts[3 * i1], a.rc.verts[3 * i1 + 1], a.rc.verts[3 * i1 + 2]);
+                const float d2 = kp_distance(cl, a.rc.verts[3 * i2], a.rc.verts[3 * i2 + 1], a.rc.verts[3 * i2 + 2]);
+                sampled = (b[0] * d0 + b[1] * d1) + b[2] * d2;
+            }
+        }
+        const float own = kp_distance(cl, X0, X1, X2);
+        a.out_vis[(size_t)n * V + v] = fabsf(sampled - own) < a.dist_thr ? 1 : 0;
+    }
+}
+
+extern "C" int nemo_project_keypoints(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                      const float* principal, int32_t n, float dist_thr, int32_t restrict_to_boundary,
+                                      float* out_kp, uint8_t* out_vis, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!m || !campos || !theta || !out_kp || !out_vis || n < 0) return fail(NEMO_ERR_INVALID, "nemo_project_keypoints: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    KeypointVisArgs a;
+    a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.outward = 0;
+    for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
+    a.rc.face_bits = 0; a.rc.depth_margin = 0.0f; a.rc.depth_scale = 0.0f; a.rc.depth_qmax = 0.0f;
+    a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kRasterThreads, &a.rc.L);
+    if (rcode) return rcode;
+    a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
+    a.focal = cam->focal; a.dist_thr = dist_thr; a.clamp_to_image = restrict_to_boundary != 0;
+    a.out_kp = out_kp; a.out_vis = out_vis;
+    auto kern = a.rc.L.faces >= 0 ? keypoint_vis_kernel<true> : keypoint_vis_kernel<false>;
+    if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // feature-bank bookkeeping of multi-object batches (kernels in bank_ops.hip)
 // ------------------------------------------------------------------------------------------
 extern "C" int nemo_gather_features(const float* feat, const float* weight, const int32_t* input_valid, const int32_t* bank_shifts,

@@ -100,6 +100,20 @@ def project(mesh, cam, campos, theta, principal=None):
     return rt, proj
 
 
+def project_keypoints(mesh, cam, campos, theta, principal=None, dist_thr=1e-3, restrict_to_boundary=True):
+    """Training-side annotation: -> (kp [n,V,2] = (y, x) feature-map pixels, vis [n,V] bool)."""
+    lib = _lib.load()
+    cp, th, pr, n = _pose_args(campos, theta, principal)
+    kp = torch.empty(n, mesh.V, 2, device=cp.device)
+    vis = torch.empty(n, mesh.V, dtype=torch.uint8, device=cp.device)
+    cc = cam.c()
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_project_keypoints(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, float(dist_thr),
+                                         1 if restrict_to_boundary else 0, ptr(kp), ptr(vis, torch.uint8), stream_ptr()),
+              "nemo_project_keypoints")
+    return kp, vis.bool()
+
+
 def render(mesh, cam, campos, theta, principal=None, maps=True, fragments=False):
     """-> dict(maps [n,C,H,W], pix_to_face [n,H,W] i32, bary [n,H,W,3], zbuf [n,H,W]) (requested keys)."""
     lib = _lib.load()

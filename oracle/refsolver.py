@@ -771,3 +771,38 @@ def synthetic_feature_map(inter, clutter, seed, noise=0.5):
     m = m + noise * torch.randn(m.shape, generator=g) / math.sqrt(m.shape[-1])
     m = torch.nn.functional.normalize(m, dim=-1)
     return m.permute(2, 0, 1).contiguous(), gt
+
+
+# --------------------------------------------------------------------------------------
+# training-side keypoint annotation (nemo/models/project_kp.py:175-247, one mesh per pose)
+# --------------------------------------------------------------------------------------
+def project_keypoints(verts, faces, campos, theta, cam, principal=None, restrict_to_boundary=True, dist_thr=1e-3):
+    """get_one_standard (project_kp.py:175-247) with func_single: -> (project_verts [n,V,2] as (y, x) in
+    feature-map pixels, vis_mask [n,V] bool, margin [n,V] = | |sampled - true| - dist_thr | for tests that
+    want to skip vertices sitting on the threshold).  The PyTorch3D pinhole is restated as
+    x_t = (f X + px Z) / Z (PerspectiveCameras(in_ndc=False).transform_points: K then divide by w)."""
+    n, V = campos.shape[0], verts.shape[0]
+    R, T = R_T_tensors(campos, theta)                      # X_view = X @ R + T
+    pr = torch.tensor([cam.principal], dtype=torch.float32).expand(n, 2) if principal is None else principal.float()
+    cam_loc = -torch.matmul(torch.inverse(R), T[..., None])[:, :, 0]                       # :183
+    _, _, _, Xv = project_verts(verts, campos, theta, cam, principal)
+    xt = (cam.focal * Xv[0] + pr[:, 0:1] * Xv[2]) / Xv[2]
+    yt = (cam.focal * Xv[1] + pr[:, 1:2] * Xv[2]) / Xv[2]
+    project = torch.stack([2 * pr[:, 1:2] - yt, 2 * pr[:, 0:1] - xt], dim=-1)            # :186-188, (y, x)
+    size = torch.tensor([[float(cam.H), float(cam.W)]])
+    if restrict_to_boundary:                                                               # :194-197
+        project = torch.min(project, (size.unsqueeze(1) - 1) * torch.ones_like(project))
+        project = torch.max(project, torch.zeros_like(project))
+    p2f, bary, _ = fragments(verts, faces, campos, theta, cam, principal)
+    true_dist = (cam_loc[:, None] - verts[None]).pow(2).sum(-1).pow(.5)                   # [n,V] :201
+    face_dist = true_dist[:, faces.long()]                                                # [n,F,3] :202
+    depth = torch.zeros(n, cam.H, cam.W)
+    for i in range(n):
+        cov = p2f[i] >= 0
+        fd = face_dist[i][p2f[i][cov]]                                                    # [m,3]
+        b = bary[i][cov].detach()
+        depth[i][cov] = (b[:, 0] * fd[:, 0] + b[:, 1] * fd[:, 1]) + b[:, 2] * fd[:, 2]     # interpolate_face_attributes :209
+    grid = project[:, None] / size * 2 - 1                                                # :211
+    sampled = torch.nn.functional.grid_sample(depth[:, None], grid.flip(-1), align_corners=False, mode="nearest")[:, 0, 0, :]
+    diff = torch.abs(sampled - true_dist)
+    return project, diff < dist_thr, torch.abs(diff - dist_thr)

@@ -781,3 +781,41 @@ def test_grid_pack_falls_back_for_other_channel_counts(gpu):
     C0, th0, mn = nemo_amd.batch_solve_pose.get_init_pos_rendered_dim0(maps, cs, ths, fm.to(gpu), clu.to(gpu))
     assert torch.equal(C0.cpu(), cs.cpu()[loss_ref.argmin(dim=1)])
     assert torch.allclose(mn.cpu(), loss_ref.min(dim=1)[0], rtol=REL, atol=0)
+
+
+@pytest.mark.parametrize("dist_thr,with_principal,restrict", [(1e-3, False, True), (0.05, True, True), (0.05, False, False)])
+def test_packed_raster_keypoints_and_visibility(small, dist_thr, with_principal, restrict):
+    """Training-side annotation (PackedRaster / get_one_standard): projected vertices within 1e-4 pixel of the
+    oracle, visibility identical except for vertices sitting on a decision boundary (distance difference within
+    1e-5 of the threshold, or projection within 1e-3 pixel of the line between two pixels)."""
+    from nemo_amd.project_kp import PackedRaster
+    sc = small
+    cfgs = dict(type="near", image_size=(sc.H * 8, sc.W * 8), down_rate=8, focal_length=sc.cam.focal * 8)
+    pr = PackedRaster(cfgs, (sc.verts, sc.faces), device=sc.device)
+    n = 6
+    g = torch.Generator().manual_seed(11)
+    azim, elev = torch.rand(n, generator=g) * 2 * math.pi, (torch.rand(n, generator=g) - 0.3) * 1.2
+    theta = (torch.rand(n, generator=g) - 0.5) * 0.6
+    dist = torch.tensor([5.0, 5.0, 4.0, 6.0, 2.0, 1.2])          # the last two fill / overflow the map
+    principal = None
+    if with_principal:
+        principal = torch.tensor([[sc.W * 4.0, sc.H * 4.0]]).repeat(n, 1) + 40.0 * (torch.rand(n, 2, generator=g) - 0.5)
+    kw = dict(dist_thr=dist_thr, restrict_to_boundary=restrict)
+    if principal is not None:
+        kw["principal"] = principal
+    kp, vis = pr(azim, elev, dist, theta, **kw)
+    campos = R.camera_position_from_spherical_angles(dist, elev, azim)
+    verts = sc.verts if torch.is_tensor(sc.verts) else torch.from_numpy(sc.verts)
+    rkp, rvis, margin = R.project_keypoints(verts, torch.as_tensor(sc.faces), campos, theta, sc.cam,
+                                            principal=None if principal is None else principal / 8,
+                                            restrict_to_boundary=restrict, dist_thr=dist_thr)
+    assert kp.shape == rkp.shape and vis.dtype == torch.bool
+    assert float((kp.cpu() - rkp).abs().max()) < 1e-4 * max(1.0, float(rkp.abs().max()) / 50.0)
+    frac = (rkp - 0.5) - torch.floor(rkp - 0.5)                      # position between two pixel centres
+    on_line = ((frac - 0.5).abs() < 1e-3).any(dim=-1)
+    decided = (margin > 1e-5) & ~on_line
+    assert float(decided.float().mean()) > 0.5              # (clamped coordinates are whole numbers: "on the line")
+    assert torch.equal(vis.cpu()[decided], rvis[decided])
+    assert float((vis.cpu() != rvis).float().mean()) < 0.01  # and the undecided ones almost never differ either
+    if dist_thr > 1e-2:
+        assert 0.1 < float(rvis.float().mean()) < 0.9                # a real mix of visible and hidden vertices
