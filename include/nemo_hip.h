@@ -144,6 +144,20 @@ int nemo_grid_score_packed(const void* packed, const float* feat, const float* c
                            int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Scoring of re-centred copies of a batch, the 6-D initialisation loop of batch_solve_pose.py:264-295 (every
+ * principal-point sample re-centres the whole batch with align_no_centered, :65-90, and scores it against the
+ * grid): virtual image bv is source image bv % B_src resampled with (dist_src, dist_tgt, p_src, p_tgt)[bv] as
+ * nemo_align_maps does, and scored like nemo_grid_score_packed - but the resampled feature maps are never written:
+ * the fragment kernel samples the source maps directly.  feat [B_src,C,h1*w1], clu [B_src,h1*w1] or NULL,
+ * packed = nemo_grid_pack of the [N,C,h0*w0] grid; outputs [n_virtual,N], [n_virtual], [n_virtual].  Same numbers
+ * as nemo_align_maps followed by nemo_grid_score_packed, bit for bit. */
+size_t nemo_grid_score_recentred_workspace(int32_t N, int32_t n_virtual, int32_t C, int32_t h0, int32_t w0);
+int nemo_grid_score_recentred(const void* packed, const float* feat, const float* clu, const float* dist_src,
+                              const float* dist_tgt, const float* p_src, const float* p_tgt, int32_t N, int32_t B_src,
+                              int32_t n_virtual, int32_t C, int32_t h1, int32_t w1, int32_t h0, int32_t w0,
+                              int32_t border, float* out_loss, int32_t* out_argmin, float* out_min, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- vertex x pixel similarity table --------------------------------------------------------
  * table[b,v,p] = sum_c memory[v,c] * feat[b,c,p]: the reference's kpt_score_map
  * (nemo/models/solve_pose.py:120-124) and the matmul of NeMo.fast_inference

@@ -182,13 +182,24 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
         # streamed once per launch instead of once per sample; results per sample are unchanged.
         all_C, all_theta, all_loss = [], [], []
         per_call = max(1, 1024 // max(b, 1))
+        packed = getattr(feature_pre_rendered, "_nemo_packed_grid", None)
         for s0 in range(0, principal.shape[0], per_call):
             chunk = principal[s0:s0 + per_call]
-            fms = [align_no_centered(feature_map, ones, p_, target_shape, ones, centre, padding_mode="border") for p_ in chunk]
-            cls = [align_no_centered(clutter_score[:, None], ones, p_, target_shape, ones, centre, padding_mode="border").squeeze(1)
-                   for p_ in chunk]
-            C_, th_, loss_ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered,
-                                                        torch.cat(fms), torch.cat(cls))
+            if packed is not None:
+                # the re-centred copies are never written: the scoring samples the batch's own maps (copy k * b + i
+                # = image i re-centred on principal sample k)
+                nv = chunk.shape[0] * b
+                ones_v = torch.ones(nv, device=dev)
+                _, idx_, loss_ = ops.grid_score_recentred(packed, feature_map, clutter_score, ones_v, ones_v,
+                                                          chunk.repeat_interleave(b, dim=0), centre.to(dev).expand(nv, 2),
+                                                          padding_mode="border")
+                C_, th_ = cam_pos_pre_rendered[idx_.long()], theta_pre_rendered[idx_.long()]
+            else:
+                fms = [align_no_centered(feature_map, ones, p_, target_shape, ones, centre, padding_mode="border") for p_ in chunk]
+                cls = [align_no_centered(clutter_score[:, None], ones, p_, target_shape, ones, centre, padding_mode="border").squeeze(1)
+                       for p_ in chunk]
+                C_, th_, loss_ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered,
+                                                            torch.cat(fms), torch.cat(cls))
             for k in range(chunk.shape[0]):
                 all_C.append(C_[k * b:(k + 1) * b])
                 all_theta.append(th_[k * b:(k + 1) * b])

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "split_f16.h"
+#include "resample.h"
 
 namespace nemo {
 
@@ -92,6 +93,61 @@ __global__ __launch_bounds__(256) void grid_feat_kernel(const float* __restrict_
         uint4 pcs[SG_NP];
         split8(x, pcs);
         const size_t base = (((size_t)p * ncb + cb) * nks + ks) * 2;
+        featp[(base + 0) * 64 + lane] = pcs[0];
+        featp[(base + 1) * 64 + lane] = pcs[1];
+    }
+}
+
+// The same for re-centred copies of a batch (6-D initialisation, batch_solve_pose.py:264-295): virtual image
+// bv is source image bv % Bsrc resampled with its own re-centring parameters (resample.h).  The resampled maps
+// are never written: the four taps of a (virtual image, pixel) are worked out once per brick row group and
+// the brick is filled with the bilinear values.
+struct RecentreArgs {
+    const float* dist_src; const float* dist_tgt; const float* p_src; const float* p_tgt;     // per virtual image
+    int Bsrc, h1, w1, h0, w0, border;
+};
+
+__global__ __launch_bounds__(256) void grid_feat_recentred_kernel(const float* __restrict__ feat, uint4* __restrict__ featp, int B,
+                                                                  int C, int ncb, RecentreArgs ra) {
+    __shared__ float brick[32 * GF_IMG_STRIDE];
+    const int nks = C / 16, HW = ra.h0 * ra.w0, HW1 = ra.h1 * ra.w1;
+    const int p0 = blockIdx.x * GF_PX, ks = blockIdx.y, cb = blockIdx.z;
+    const int px = threadIdx.x & 31;
+    const int p = p0 + px;
+    const int pc = p < HW ? p : HW - 1;
+    const int ty = pc / ra.w0, tx = pc - ty * ra.w0;
+    // brick rows r = image * 16 + channel; a thread handles rows r0 + 8 u: image (r0 >> 4) + ... two channels per image
+#pragma unroll 1
+    for (int r0 = threadIdx.x >> 5; r0 < 32 * 16; r0 += 8 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            const int r = r0 + 8 * u, img = r >> 4;
+            const int b = min(cb * 32 + img, B - 1);
+            const AlignTaps t = align_taps(ra.dist_src[b], ra.dist_tgt[b], ra.p_src[2 * b], ra.p_src[2 * b + 1], ra.p_tgt[2 * b],
+                                           ra.p_tgt[2 * b + 1], ra.h1, ra.w1, ra.h0, ra.w0, ra.border, tx, ty);
+            const float* sp = feat + ((size_t)(b % ra.Bsrc) * C + ks * 16) * HW1;
+            v[u] = align_sample(sp + (size_t)(r & 15) * HW1, t);
+            v[u + 1] = align_sample(sp + (size_t)((r + 8) & 15) * HW1, t);          // row r + 8: same image, channel + 8
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = r0 + 8 * u, img = r >> 4, ch = r & 15;
+            brick[img * GF_IMG_STRIDE + ch * (GF_PX + 1) + px] = (cb * 32 + img < B && p < HW) ? v[u] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int img = lane & 31, kq = lane >> 5;
+    for (int q = wave; q < GF_PX; q += 4) {
+        const int pq = p0 + q;
+        if (pq >= HW) break;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = scale_clamp(brick[img * GF_IMG_STRIDE + (8 * kq + j) * (GF_PX + 1) + q]);
+        uint4 pcs[SG_NP];
+        split8(x, pcs);
+        const size_t base = (((size_t)pq * ncb + cb) * nks + ks) * 2;
         featp[(base + 0) * 64 + lane] = pcs[0];
         featp[(base + 1) * 64 + lane] = pcs[1];
     }
@@ -236,6 +292,28 @@ int launch_grid_mfma(const void* packed, const float* feat, const float* clu, in
     (void)nrb;
     hipLaunchKernelGGL(grid_feat_kernel, dim3((HW + GF_PX - 1) / GF_PX, C / 16, ncb), dim3(256), 0, st, feat, (uint4*)featp, B, C, HW,
                        ncb);
+    switch (C / 16) {
+        case 1: launch_mfma_nks<1>(packed, featp, clu, N, B, HW, partial, st); break;
+        case 2: launch_mfma_nks<2>(packed, featp, clu, N, B, HW, partial, st); break;
+        case 4: launch_mfma_nks<4>(packed, featp, clu, N, B, HW, partial, st); break;
+        case 8: launch_mfma_nks<8>(packed, featp, clu, N, B, HW, partial, st); break;
+        default: return -2;
+    }
+    return 0;
+}
+
+// The same with the feature fragments built from re-centred copies: B virtual images of Bsrc source maps
+// (h1 x w1), scored on the h0 x w0 grid maps; clu [B, h0 * w0] already re-centred (or null).
+int launch_grid_mfma_recentred(const void* packed, const float* feat_src, const float* clu, int N, int B, int C, int Bsrc, int h1, int w1,
+                               int h0, int w0, int border, const float* dist_src, const float* dist_tgt, const float* p_src,
+                               const float* p_tgt, void* featp, float* partial, hipStream_t st) {
+    const int ncb = (B + 31) / 32, HW = h0 * w0;
+    if (ncb > 65535) return -1;
+    RecentreArgs ra;
+    ra.dist_src = dist_src; ra.dist_tgt = dist_tgt; ra.p_src = p_src; ra.p_tgt = p_tgt;
+    ra.Bsrc = Bsrc; ra.h1 = h1; ra.w1 = w1; ra.h0 = h0; ra.w0 = w0; ra.border = border;
+    hipLaunchKernelGGL(grid_feat_recentred_kernel, dim3((HW + GF_PX - 1) / GF_PX, C / 16, ncb), dim3(256), 0, st, feat_src,
+                       (uint4*)featp, B, C, ncb, ra);
     switch (C / 16) {
         case 1: launch_mfma_nks<1>(packed, featp, clu, N, B, HW, partial, st); break;
         case 2: launch_mfma_nks<2>(packed, featp, clu, N, B, HW, partial, st); break;

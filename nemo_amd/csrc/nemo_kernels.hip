@@ -24,6 +24,7 @@
 
 #include "../../include/nemo_hip.h"
 #include "raster.h"
+#include "resample.h"
 
 #pragma clang fp contract(off)
 
@@ -170,6 +171,9 @@ void launch_mask_weight(const int32_t* object_idx, const int32_t* source_vert_id
 bool split_table_supported(int C);
 size_t split_bank_bytes(int V, int C);
 void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_t st);
+int launch_grid_mfma_recentred(const void* packed, const float* feat_src, const float* clu, int N, int B, int C, int Bsrc, int h1, int w1,
+                               int h0, int w0, int border, const float* dist_src, const float* dist_tgt, const float* p_src,
+                               const float* p_tgt, void* featp, float* partial, hipStream_t st);
 int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
 }
 
@@ -562,41 +566,20 @@ extern "C" int nemo_clutter_score(const float* feat, const float* clutter, int32
 //   gx(x) = (1 - t_x) * x_min[n] + t_x * x_max[n],  t_x = x / (w0 - 1)     (same for y)
 // with  x_min/max = 2 ps_x / w1 -/+ w0 / (w1 * rate) - 2 pt_x / w0,  rate = dist_source / dist_target.
 // border != 0: coordinates are clamped to the source (padding_mode='border'), else taps outside read 0.
+// src_count: map n reads source image n % src_count (several re-centred copies of one batch in one launch)
 __global__ void align_kernel(const float* __restrict__ src, const float* __restrict__ dist_src,
                              const float* __restrict__ dist_tgt, const float* __restrict__ p_src,
-                             const float* __restrict__ p_tgt, int C, int h1, int w1, int h0, int w0, int border,
+                             const float* __restrict__ p_tgt, int C, int h1, int w1, int h0, int w0, int border, int src_count,
                              float* __restrict__ out) {
     const int n = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= h0 * w0) return;
     const int y = q / w0, x = q - y * w0;
-    const float rate = dist_src[n] / dist_tgt[n];
-    const float psx = p_src[2 * n], psy = p_src[2 * n + 1], ptx = p_tgt[2 * n], pty = p_tgt[2 * n + 1];
-    const float fw0 = (float)w0, fh0 = (float)h0, fw1 = (float)w1, fh1 = (float)h1;
-    const float xmin = 2.0f * psx / fw1 - fw0 / (fw1 * rate) - ptx * 2.0f / fw0;
-    const float xmax = 2.0f * psx / fw1 + fw0 / (fw1 * rate) - ptx * 2.0f / fw0;
-    const float ymin = 2.0f * psy / fh1 - fh0 / (fh1 * rate) - pty * 2.0f / fh0;
-    const float ymax = 2.0f * psy / fh1 + fh0 / (fh1 * rate) - pty * 2.0f / fh0;
-    const float tx = w0 > 1 ? (float)x / (float)(w0 - 1) : 0.0f, ty = h0 > 1 ? (float)y / (float)(h0 - 1) : 0.0f;
-    const float gx = (1.0f - tx) * xmin + tx * xmax, gy = (1.0f - ty) * ymin + ty * ymax;
-    float ix = ((gx + 1.0f) * fw1 - 1.0f) / 2.0f, iy = ((gy + 1.0f) * fh1 - 1.0f) / 2.0f;
-    if (border) {
-        ix = fminf(fmaxf(ix, 0.0f), fw1 - 1.0f);
-        iy = fminf(fmaxf(iy, 0.0f), fh1 - 1.0f);
-    }
-    const float fx0 = floorf(ix), fy0 = floorf(iy);
-    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
-    const float wx1 = ix - fx0, wx0 = 1.0f - wx1, wy1 = iy - fy0, wy0 = 1.0f - wy1;
-    const bool vx0 = x0 >= 0 && x0 < w1, vx1 = x1 >= 0 && x1 < w1, vy0 = y0 >= 0 && y0 < h1, vy1 = y1 >= 0 && y1 < h1;
-    const int cx0 = min(max(x0, 0), w1 - 1), cx1 = min(max(x1, 0), w1 - 1), cy0 = min(max(y0, 0), h1 - 1), cy1 = min(max(y1, 0), h1 - 1);
-    const float w00 = (vx0 && vy0) ? wx0 * wy0 : 0.0f, w01 = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
-    const float w10 = (vx0 && vy1) ? wx0 * wy1 : 0.0f, w11 = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
-    const float* sp = src + (size_t)n * C * h1 * w1;
+    const AlignTaps t = align_taps(dist_src[n], dist_tgt[n], p_src[2 * n], p_src[2 * n + 1], p_tgt[2 * n], p_tgt[2 * n + 1], h1, w1, h0,
+                                   w0, border, x, y);
+    const float* sp = src + (size_t)(n % src_count) * C * h1 * w1;
     float* op = out + (size_t)n * C * h0 * w0 + q;
-    for (int c = 0; c < C; ++c) {
-        const float* sc = sp + (size_t)c * h1 * w1;
-        op[(size_t)c * h0 * w0] = sc[cy0 * w1 + cx0] * w00 + sc[cy0 * w1 + cx1] * w01 + sc[cy1 * w1 + cx0] * w10 + sc[cy1 * w1 + cx1] * w11;
-    }
+    for (int c = 0; c < C; ++c) op[(size_t)c * h0 * w0] = align_sample(sp + (size_t)c * h1 * w1, t);
 }
 
 extern "C" int nemo_align_maps(const float* src, const float* dist_src, const float* dist_tgt, const float* p_src,
@@ -608,7 +591,7 @@ extern "C" int nemo_align_maps(const float* src, const float* dist_src, const fl
     if (n > 65535) return fail(NEMO_ERR_UNSUPPORTED, "nemo_align_maps: more than 65535 maps per call");
     dim3 grid((h0 * w0 + 255) / 256, n);
     hipLaunchKernelGGL(align_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dist_src, dist_tgt, p_src, p_tgt, C, h1,
-                       w1, h0, w0, border, out);
+                       w1, h0, w0, border, n, out);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }
@@ -793,6 +776,48 @@ extern "C" int nemo_grid_score_packed(const void* packed, const float* feat, con
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)partial, clu, N, B, HW, nemo::grid_chunks(HW),
                        out_loss, out_argmin, out_min);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// Pose-grid scoring of re-centred copies of a batch without writing the copies (6-D initialisation):
+// virtual image bv = source image bv % B_src resampled with (dist_src, dist_tgt, p_src, p_tgt)[bv].
+extern "C" size_t nemo_grid_score_recentred_workspace(int32_t N, int32_t n_virtual, int32_t C, int32_t h0, int32_t w0) {
+    const size_t base = nemo_grid_score_packed_workspace(N, n_virtual, C, h0 * w0);
+    return base ? align256(base) + (size_t)n_virtual * h0 * w0 * sizeof(float) : 0;
+}
+
+extern "C" int nemo_grid_score_recentred(const void* packed, const float* feat, const float* clu, const float* dist_src,
+                                         const float* dist_tgt, const float* p_src, const float* p_tgt, int32_t N, int32_t B_src,
+                                         int32_t n_virtual, int32_t C, int32_t h1, int32_t w1, int32_t h0, int32_t w0,
+                                         int32_t border, float* out_loss, int32_t* out_argmin, float* out_min, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (n_virtual == 0) return NEMO_OK;
+    if (!packed || !feat || !dist_src || !dist_tgt || !p_src || !p_tgt || !out_argmin || N <= 0 || B_src <= 0 || n_virtual < 0 ||
+        C <= 0 || h1 <= 0 || w1 <= 0 || h0 <= 0 || w0 <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_recentred: bad argument");
+    if (!nemo::grid_mfma_supported(C))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_recentred: %d channels (takes 16, 32, 64 or 128)", C);
+    if (n_virtual > 65535) return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_recentred: more than 65535 copies per call");
+    const int HW = h0 * w0;
+    const size_t need = nemo_grid_score_recentred_workspace(N, n_virtual, C, h0, w0);
+    if (!workspace || workspace_bytes < need)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_recentred: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)((char*)workspace + align256(nemo::grid_feat_bytes(n_virtual, C, HW)));
+    float* clu_v = nullptr;
+    if (clu) {          // the clutter maps are small: re-centred into the workspace by the one-channel resample
+        clu_v = (float*)((char*)workspace + align256(nemo_grid_score_packed_workspace(N, n_virtual, C, HW)));
+        dim3 grid((HW + 255) / 256, n_virtual);
+        hipLaunchKernelGGL(align_kernel, grid, dim3(256), 0, st, clu, dist_src, dist_tgt, p_src, p_tgt, 1, h1, w1, h0, w0, border, B_src,
+                           clu_v);
+    }
+    if (nemo::launch_grid_mfma_recentred(packed, feat, clu_v, N, n_virtual, C, B_src, h1, w1, h0, w0, border, dist_src, dist_tgt, p_src,
+                                         p_tgt, workspace, partial, st))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_recentred: batch too large for one launch");
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grid_finalize_kernel, dim3(n_virtual), dim3(256), 0, st, (const float*)partial, (const float*)clu_v, N, n_virtual,
+                       HW, nemo::grid_chunks(HW), out_loss, out_argmin, out_min);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

@@ -224,6 +224,38 @@ def grid_score(pre_rendered, feature_map, clutter_score_map=None, packed=None):
     return loss, amin, mn
 
 
+def grid_score_recentred(packed, feature_map, clutter_score_map, dist_src, dist_tgt, p_src, p_tgt, padding_mode="border"):
+    """Scores re-centred copies of a batch against a packed grid without materialising them.
+    feature_map [B,C,h1,w1], clutter_score_map [B,h1,w1] or None; dist_src / dist_tgt [nv], p_src / p_tgt [nv,2]
+    (x, y): copy bv is image bv % B re-centred like align_maps.  -> (loss [nv,N], argmin [nv] i32, min [nv])."""
+    lib = _lib.load()
+    fm = f32c(feature_map)
+    B, Cc, h1, w1 = fm.shape
+    N, Cg, h0, w0 = packed.shape
+    if Cg != Cc:
+        raise ValueError(f"feature_map has {Cc} channels, the packed grid {Cg}")
+    if padding_mode not in ("zeros", "border"):
+        raise NotImplementedError("padding_mode must be 'zeros' or 'border'")
+    nv = int(dist_src.numel())
+    args = [f32c(t.to(fm.device)).reshape(nv, -1).contiguous() for t in (dist_src, dist_tgt, p_src, p_tgt)]
+    if args[2].shape[1] != 2 or args[3].shape[1] != 2:
+        raise ValueError("p_src / p_tgt must be [nv, 2]")
+    clu = None if clutter_score_map is None else f32c(clutter_score_map).reshape(B, h1 * w1)
+    loss = torch.empty(nv, N, device=fm.device)
+    amin = torch.empty(nv, dtype=torch.int32, device=fm.device)
+    mn = torch.empty(nv, device=fm.device)
+    nbytes = lib.nemo_grid_score_recentred_workspace(N, nv, Cc, h0, w0)
+    if nbytes == 0:
+        raise NotImplementedError(f"grid_score_recentred takes 16, 32, 64 or 128 channels, not {Cc}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=fm.device)
+    with torch.cuda.device(fm.device):
+        check(lib.nemo_grid_score_recentred(ptr(packed.data, torch.uint8), ptr(fm), ptr(clu), ptr(args[0]), ptr(args[1]), ptr(args[2]),
+                                            ptr(args[3]), N, B, nv, Cc, h1, w1, h0, w0, 1 if padding_mode == "border" else 0,
+                                            ptr(loss), ptr(amin, torch.int32), ptr(mn), ptr(ws, torch.uint8), nbytes, stream_ptr()),
+              "nemo_grid_score_recentred")
+    return loss, amin, mn
+
+
 TABLE_TILE = 128
 
 

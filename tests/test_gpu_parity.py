@@ -819,3 +819,34 @@ def test_packed_raster_keypoints_and_visibility(small, dist_thr, with_principal,
     assert float((vis.cpu() != rvis).float().mean()) < 0.01  # and the undecided ones almost never differ either
     if dist_thr > 1e-2:
         assert 0.1 < float(rvis.float().mean()) < 0.9                # a real mix of visible and hidden vertices
+
+
+@pytest.mark.parametrize("padding_mode", ["border", "zeros"])
+def test_grid_score_recentred_equals_align_then_score(small, padding_mode):
+    """Scoring re-centred copies straight from the batch's maps: the same bits as re-centring every copy with
+    align_maps and scoring the copies."""
+    import nemo_amd
+    from nemo_amd import ops
+    sc = small
+    az, el, th, _, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, np.array([4.0, 6.0]))
+    packed = maps._nemo_packed_grid
+    B, S = 3, 5
+    fm, _ = sc.feature_maps(B, first_seed=90)
+    fmd = fm.to(sc.device)
+    clu = ops.clutter_score(fmd, sc.clutter.to(sc.device))
+    g = torch.Generator().manual_seed(4)
+    nv = S * B
+    p_src = (torch.tensor([[sc.W / 2.0, sc.H / 2.0]]) + 14.0 * (torch.rand(S, 2, generator=g) - 0.5)).repeat_interleave(B, dim=0).to(sc.device)
+    p_tgt = torch.tensor([[sc.W / 2.0, sc.H / 2.0]]).expand(nv, 2).contiguous().to(sc.device)
+    d_src = (0.8 + 0.4 * torch.rand(nv, generator=g)).to(sc.device)
+    d_tgt = torch.ones(nv, device=sc.device)
+    loss, amin, mn = ops.grid_score_recentred(packed, fmd, clu, d_src, d_tgt, p_src, p_tgt, padding_mode=padding_mode)
+    copies = ops.align_maps(fmd.repeat(S, 1, 1, 1), d_src, p_src, (sc.H, sc.W), d_tgt, p_tgt, padding_mode)
+    clu_c = ops.align_maps(clu[:, None].repeat(S, 1, 1, 1), d_src, p_src, (sc.H, sc.W), d_tgt, p_tgt, padding_mode).squeeze(1)
+    loss2, amin2, mn2 = ops.grid_score(None, copies, clu_c, packed=packed)
+    assert torch.equal(loss, loss2) and torch.equal(amin, amin2) and torch.equal(mn, mn2)
+    # and without a clutter map
+    loss3, amin3, _ = ops.grid_score_recentred(packed, fmd, None, d_src, d_tgt, p_src, p_tgt, padding_mode=padding_mode)
+    loss4, amin4, _ = ops.grid_score(None, copies, None, packed=packed)
+    assert torch.equal(loss3, loss4) and torch.equal(amin3, amin4)
