@@ -67,9 +67,10 @@ def synthetic_images(mod, clutter, B, first_seed, dev):
     return torch.nn.functional.normalize(maps, dim=1).contiguous(), dict(azimuth=az, elevation=el, theta=th)
 
 
-def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=100):
+def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=EPOCHS):
     """The oracle (PyTorch-CPU restatement of the reference's PyTorch3D CPU path) on this host's cores,
-    on a bounded sample of the same workload: grid scoring of one image + n_steps Adam steps at B=1."""
+    on a bounded sample of the same workload: one whole image (grid scoring + all Adam steps) at B=1, about
+    ten seconds of CPU work."""
     from oracle import refsolver as R
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
     cores = torch.get_num_threads()
@@ -88,7 +89,7 @@ def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=100):
     return dict(value=1.0 / t_opt, unit="hypothesis-steps/s", cores=cores, kind="port",
                 sample=f"oracle/refsolver.py at B=1, {H}x{W}x{C}, V={v.shape[0]} F={f.shape[0]}: grid scoring of 1 image x "
                        f"{maps.shape[0]} poses ({t_grid:.2f} s) + {n_steps} Adam steps ({t_opt:.3f} s each); "
-                       f"images/s extrapolated to {EPOCHS} steps",
+                       f"images/s = 1 / (grid + {EPOCHS} steps)",
                 images_per_sec=1.0 / per_image)
 
 
@@ -259,6 +260,18 @@ def main():
                 tj = json.load(fh)
             if tj.get("hypotheses_per_launch") == G * B * K_HYP and tj.get("adam_steps") == EPOCHS:
                 traffic = (tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0
+        # the kernels in front of the solve are HBM-bound streams: algorithmic bytes of one launch over G*B images
+        n_img = G * B
+        fm_bytes = C * H * W * 4
+        table_bytes = 4 * math.prod(ops.table_shape(mod.mesh, 1, H * W))
+        front = {
+            "similarity_table": n_img * (table_bytes + fm_bytes),                       # table written once, maps read once
+            "grid_score": -(-n_img // 256) * packed.data.numel() + 3 * n_img * fm_bytes,  # packed grid per 256 images; maps read, fragments written + read
+            "clutter_score": n_img * (fm_bytes + H * W * 4),
+        }
+        other = {k: {"bound": "hbm", "achieved": b / (kern_ms[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b / (kern_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b}
+                 for k, b in front.items()}
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -280,6 +293,7 @@ def main():
                                  "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
                                  "kernel reads a precomputed vertex x pixel similarity table instead (3 floats per covered pixel), "
                                  "so frac > 1 means it beats the streaming roofline; see DESIGN.md"},
+            "front_kernel_rooflines": other,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mod, mem, clutter, v, f, fm_g[0], pre, cs, ths)

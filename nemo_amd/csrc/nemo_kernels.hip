@@ -896,6 +896,12 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     const int h = blockIdx.x, tid = threadIdx.x;
     const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
     const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
+    if ((unsigned)img >= (unsigned)a.n_img) {      // a hypothesis that names no image: NaN row, nothing read
+        if (tid < 8) a.out_pose[(size_t)h * 8 + tid] = __builtin_nanf("");
+        if (a.out_hist)
+            for (int k = tid; k < a.steps; k += blockDim.x) a.out_hist[(size_t)h * a.steps + k] = __builtin_nanf("");
+        return;
+    }
     const float* tab = a.table + (size_t)img * table_image_elems(V, HW);
     const int vg_n = (V + 3) >> 2;
     const float* clu = a.clu + (size_t)img * HW;

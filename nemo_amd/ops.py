@@ -71,6 +71,17 @@ class MeshHandle:
             pass
 
 
+def _image_index(hyp_to_image, n_img, device):
+    """hyp_to_image as int32 on `device`.  A host tensor is range-checked here; a device tensor is not read
+    back (no synchronisation in the solve path): the kernel gives a hypothesis whose index names no image a
+    NaN result row instead."""
+    if hyp_to_image is None:
+        return None
+    if not hyp_to_image.is_cuda and hyp_to_image.numel() and (int(hyp_to_image.min()) < 0 or int(hyp_to_image.max()) >= n_img):
+        raise ValueError("hyp_to_image out of range")
+    return hyp_to_image.to(device=device, dtype=torch.int32).contiguous()
+
+
 def _pose_args(campos, theta, principal):
     cp = f32c(campos).reshape(-1, 3)
     n = cp.shape[0]
@@ -341,9 +352,7 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
     n_img = table.shape[0]
     if hyp_to_image is None and n_hyp != n_img:
         raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
-    h2i = None if hyp_to_image is None else hyp_to_image.to(device=cp.device, dtype=torch.int32).contiguous()
-    if h2i is not None and h2i.numel() and (int(h2i.min()) < 0 or int(h2i.max()) >= n_img):
-        raise ValueError("hyp_to_image out of range")
+    h2i = _image_index(hyp_to_image, n_img, cp.device)
     clu2 = f32c(clu).reshape(n_img, -1)
     if tuple(table.shape) != table_shape(mesh, n_img, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
         raise ValueError("table / clutter shapes do not match the mesh and camera")
@@ -395,9 +404,7 @@ def solve_flow(mesh, cam, table, clu, init_campos, init_theta, init_flow=None, h
     n_img = table.shape[0]
     if hyp_to_image is None and n_hyp != n_img:
         raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
-    h2i = None if hyp_to_image is None else hyp_to_image.to(device=cp.device, dtype=torch.int32).contiguous()
-    if h2i is not None and h2i.numel() and (int(h2i.min()) < 0 or int(h2i.max()) >= n_img):
-        raise ValueError("hyp_to_image out of range")
+    h2i = _image_index(hyp_to_image, n_img, cp.device)
     clu2 = f32c(clu).reshape(n_img, -1)
     if tuple(table.shape) != table_shape(mesh, n_img, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
         raise ValueError("table / clutter shapes do not match the mesh and camera")

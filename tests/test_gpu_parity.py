@@ -313,6 +313,15 @@ def test_global_batch_scaling(small):
     single, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), tab[:1], clu[:1], C0[1:2].to(sc.device), th0[1:2].to(sc.device),
                           steps=10, global_batch=4)
     assert torch.equal(multi[1], single[0])
+    # an index that names no image: rejected on the host when the list lives there; a device list is not read
+    # back, and the kernel answers that hypothesis with a NaN row (and history) while the others are untouched
+    bad = torch.tensor([0, 7, 1, -1], dtype=torch.int32)
+    with pytest.raises(ValueError):
+        ops.solve(sc.mod.mesh, sc.mod.camera(), tab[:2], clu[:2], C0.to(sc.device), th0.to(sc.device), hyp_to_image=bad, steps=10)
+    got, hist = ops.solve(sc.mod.mesh, sc.mod.camera(), tab[:2], clu[:2], C0.to(sc.device), th0.to(sc.device),
+                          hyp_to_image=bad.to(sc.device), steps=10, global_batch=4, history=True)
+    assert torch.isnan(got[1]).all() and torch.isnan(got[3]).all() and torch.isnan(hist[1]).all() and torch.isnan(hist[3]).all()
+    assert torch.equal(got[0], multi[0]) and torch.equal(got[2], multi[2]) and torch.isfinite(hist[0]).all()
 
 
 # ---- committed golden fixtures (tests/golden, made by oracle/gen_golden.py) -----------------------------
