@@ -830,6 +830,91 @@ def test_packed_raster_keypoints_and_visibility(small, dist_thr, with_principal,
         assert 0.1 < float(rvis.float().mean()) < 0.9                # a real mix of visible and hidden vertices
 
 
+def _assert_keypoints_match(kp, vis, rkp, rvis, margin):
+    """Projection within 1e-4 pixel; visibility equal wherever the oracle's decision is not on a boundary."""
+    assert float((kp.cpu() - rkp).abs().max()) < 1e-4 * max(1.0, float(rkp.abs().max()) / 50.0)
+    frac = (rkp - 0.5) - torch.floor(rkp - 0.5)
+    decided = (margin > 1e-5) & ~((frac - 0.5).abs() < 1e-3).any(dim=-1)
+    assert torch.equal(vis.cpu()[decided], rvis[decided])
+    assert float((vis.cpu() != rvis).float().mean()) < 0.01
+
+
+def test_packed_raster_mesh_per_pose_and_scenes(small):
+    """func_reselect (a mesh per pose out of several) and func_multi_select (a scene of moved meshes per pose,
+    the objects occluding each other): every pose equals the oracle's annotation of its own mesh / scene; outputs
+    are padded to the largest vertex count, padding slots never visible."""
+    from nemo_amd.project_kp import PackedRaster, func_multi_select, func_reselect
+    from nemo_amd.utils import meshelize
+    sc = small
+    va = sc.verts if torch.is_tensor(sc.verts) else torch.from_numpy(np.asarray(sc.verts))
+    fa = torch.as_tensor(np.asarray(sc.faces)).long()
+    vb_, fb_ = meshelize((-0.2, 0.2), (-0.35, 0.35), (-0.25, 0.25), 150)
+    vb, fb = torch.from_numpy(np.asarray(vb_, dtype=np.float32)), torch.from_numpy(np.asarray(fb_)).long()
+    assert vb.shape[0] != va.shape[0]
+    cfgs = dict(type="near", image_size=(sc.H * 8, sc.W * 8), down_rate=8, focal_length=sc.cam.focal * 8)
+    pr = PackedRaster(cfgs, ([va, vb], [fa, fb]), device=sc.device)
+    assert tuple(pr.get_verts_recent().shape) == (2, max(va.shape[0], vb.shape[0]), 3)
+    n = 5
+    g = torch.Generator().manual_seed(23)
+    azim, elev = torch.rand(n, generator=g) * 2 * math.pi, (torch.rand(n, generator=g) - 0.3) * 1.2
+    theta, dist = (torch.rand(n, generator=g) - 0.5) * 0.6, torch.full((n,), 5.0)
+    campos = R.camera_position_from_spherical_angles(dist, elev, azim)
+    vmax = max(va.shape[0], vb.shape[0])
+
+    labels = torch.tensor([1, 0, 0, 1, 1])
+    kp, vis = pr(azim, elev, dist, theta, func_of_mesh=func_reselect, indexs=labels, dist_thr=0.05)
+    assert tuple(kp.shape) == (n, vmax, 2) and tuple(vis.shape) == (n, vmax)
+    for i in range(n):
+        v, f = (va, fa) if labels[i] == 0 else (vb, fb)
+        rkp, rvis, margin = R.project_keypoints(v, f, campos[i:i + 1], theta[i:i + 1], sc.cam, dist_thr=0.05)
+        _assert_keypoints_match(kp[i:i + 1, :v.shape[0]], vis[i:i + 1, :v.shape[0]], rkp, rvis, margin)
+        assert not bool(vis[i, v.shape[0]:].any())
+    # every label the same: exactly the single-mesh annotator
+    one = PackedRaster(cfgs, (vb, fb), device=sc.device)
+    k1, v1 = one(azim, elev, dist, theta, dist_thr=0.05)
+    k2, v2 = pr(azim, elev, dist, theta, func_of_mesh=func_reselect, indexs=torch.ones(n, dtype=torch.long), dist_thr=0.05)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    with pytest.raises(ValueError):
+        pr(azim, elev, dist, theta, func_of_mesh=func_reselect, indexs=torch.tensor([0, 1, 2, 0, 0]))
+
+    # scenes: one or two objects per pose, the second pushed sideways and towards / away from the camera
+    def shift(x, y, z, s=1.0):
+        m = torch.eye(4)
+        m[0, 0] = m[1, 1] = m[2, 2] = s
+        m[3, :3] = torch.tensor([x, y, z])
+        return m
+    indexs = [[0, 1], [1], [1, 0], [0, 0], [1, 1]]
+    transforms = [[shift(0, 0, 0), shift(0.25, 0.1, 0.3)], [shift(0.1, 0, 0, 1.2)], [shift(-0.2, 0, 0), shift(0.2, 0.1, -0.2)],
+                  [shift(0, 0.3, 0), shift(0, -0.3, 0.1)], [shift(0, 0, 0.3), shift(0, 0, -0.3, 0.8)]]
+    kp, vis = pr(azim, elev, dist, theta, func_of_mesh=func_multi_select, indexs=indexs, transforms=transforms, dist_thr=0.05)
+    sizes = []
+    hidden_by_other = 0
+    for i in range(n):
+        vs, fs, off = [], [], 0
+        for j, m in zip(indexs[i], transforms[i]):
+            v, f = (va, fa) if j == 0 else (vb, fb)
+            vs.append(v * m[0, 0] + m[3, :3])
+            fs.append(f + off)
+            off += v.shape[0]
+        v, f = torch.cat(vs), torch.cat(fs)
+        sizes.append(v.shape[0])
+        rkp, rvis, margin = R.project_keypoints(v, f, campos[i:i + 1], theta[i:i + 1], sc.cam, dist_thr=0.05)
+        _assert_keypoints_match(kp[i:i + 1, :v.shape[0]], vis[i:i + 1, :v.shape[0]], rkp, rvis, margin)
+        assert not bool(vis[i, v.shape[0]:].any())
+        if len(indexs[i]) == 2:          # the first object alone sees more of its vertices than inside the scene
+            _, alone, _ = R.project_keypoints(vs[0], fs[0], campos[i:i + 1], theta[i:i + 1], sc.cam, dist_thr=0.05)
+            hidden_by_other += int((alone[0] & ~rvis[0, :vs[0].shape[0]]).sum())
+    assert kp.shape[1] == max(sizes)
+    assert hidden_by_other > 0           # the scenes really have one object in front of the other
+    # a [b, k, 4, 4] tensor of matrices is taken like the nested lists
+    two = [i for i in range(n) if len(indexs[i]) == 2]
+    mats = torch.stack([torch.stack(transforms[i]) for i in two])
+    kt, vt = pr(azim[two], elev[two], dist[two], theta[two], func_of_mesh=func_multi_select, indexs=torch.tensor([indexs[i] for i in two]),
+                transforms=mats, dist_thr=0.05)
+    w = kt.shape[1]
+    assert torch.equal(kt, kp[two][:, :w]) and torch.equal(vt, vis[two][:, :w])
+
+
 @pytest.mark.parametrize("padding_mode", ["border", "zeros"])
 def test_grid_score_recentred_equals_align_then_score(small, padding_mode):
     """Scoring re-centred copies straight from the batch's maps: the same bits as re-centring every copy with
