@@ -106,6 +106,9 @@ def main():
                     help="initial poses per image (the K best grid poses; BASELINE configs[2] uses 8); 1 = configs[1]")
     ap.add_argument("--streams", type=int, default=2, help="launch streams the groups alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stagger", action="store_true",
+                    help="let the groups on different launch streams start together (default: a group's clutter / grid / table "
+                         "kernels start when the previous group's have finished, i.e. beside the previous group's solve)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,12 +160,19 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}
 
+    # Staggered groups: the front kernels (clutter, grid, table: HBM / matrix-core bound) of group k+1 wait for the
+    # front kernels of group k, so they run beside solve(k) (vector-issue / latency bound) instead of beside front(k).
+    front_ev = [None]
+    stagger = not args.no_stagger and n_streams > 1
+
     def one_group(g, timed=False, host_out=None, slot=0):
         """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major).
         slot: which stream's buffers to use (the caller has made that stream current)."""
         n = g * B
         table = tables[slot]
         x = fm_g[:n]
+        if stagger and front_ev[0] is not None:
+            torch.cuda.current_stream().wait_event(front_ev[0])
         if timed:
             ev[0].record()
         clu = ops.clutter_score(x, clutter)
@@ -177,6 +187,9 @@ def main():
         if timed:
             ev[2].record()
         tab = ops.similarity_table(mod.mesh, x, out=table[:n])
+        if stagger:
+            front_ev[0] = torch.cuda.Event()
+            front_ev[0].record()
         if timed:
             ev[3].record()
         pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], hyp_to_image=h2i, global_batch=B * world, dof=3,
@@ -281,7 +294,7 @@ def main():
                                    "80x100x128 feature maps, cuboid mesh V=1118 F=1904, 144-pose pre-rendered grid scoring + "
                                    "300 Adam steps per image, random-init vertex bank",
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": int(pre.shape[0]), "adam_steps": EPOCHS,
-                       "batches_in_flight": G, "launch_streams": n_streams, "hypotheses_per_image": K_HYP,
+                       "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger, "hypotheses_per_image": K_HYP,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B * K_HYP,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
