@@ -94,6 +94,39 @@ def test_degenerate_and_empty(small):
     assert e["maps"].shape[0] == 0
 
 
+def test_largest_maps_and_size_limits(gpu):
+    """Largest maps.  The bit-exact renderer keeps 64-bit keys and a pair queue in LDS: with the 1118-vertex mesh
+    it takes up to about 11 k pixels (96 x 112 here); the optimisation loop (32-bit keys) takes 128 x 128 = a
+    1024 x 1024 image at stride 8.  Anything larger is refused with a message before any launch."""
+    from nemo_amd import ops
+    sc = Scene(96, 112, 16, 1000, 420.0, device=gpu)
+    campos, theta = random_poses(3, seed=5, dist=(3.5, 6.0))
+    out = ops.render(sc.mod.mesh, sc.mod.camera(), campos.to(gpu), theta.to(gpu), maps=True, fragments=True)
+    p2f, bary, zbuf = R.fragments(sc.ref.verts, sc.ref.faces, campos, theta, sc.cam)
+    assert (p2f >= 0).float().mean() > 0.05
+    assert_bits(out["pix_to_face"].long(), p2f, "face-index buffer (96 x 112)")
+    assert_bits(out["bary"], bary, "barycentrics (96 x 112)")
+    assert_bits(out["zbuf"], zbuf, "zbuf (96 x 112)")
+
+    big = Scene(128, 128, 16, 400, 480.0, device=gpu)
+    (Cr, thr, scores, hist), (pose, lh), _ = _solve_both(big, 2, 5)
+    per_image = torch.stack([h["per_image"] for h in hist], dim=1)
+    assert rel_err(lh, per_image) < REL
+    assert rel_err(pose[:, 0:3], Cr) < 1e-4
+    with pytest.raises(RuntimeError, match="LDS"):
+        ops.render(big.mod.mesh, big.mod.camera(), campos[:1].to(gpu), theta[:1].to(gpu))
+    for H, W in ((129, 128), (128, 129)):
+        cam = ops.Camera(H, W, 480.0)
+        tab = torch.zeros(ops.table_shape(big.mod.mesh, 1, H * W), device=gpu)
+        clu = torch.zeros(1, H * W, device=gpu)
+        with pytest.raises(RuntimeError, match="exceed"):
+            ops.solve(big.mod.mesh, cam, tab, clu, campos[:1].to(gpu), theta[:1].to(gpu), steps=2)
+        with pytest.raises(RuntimeError, match="exceed"):
+            ops.render(big.mod.mesh, cam, campos[:1].to(gpu), theta[:1].to(gpu))
+        with pytest.raises(RuntimeError, match="exceed"):
+            ops.project_keypoints(big.mod.mesh, cam, campos[:1].to(gpu), theta[:1].to(gpu))
+
+
 def test_clutter_score(full):
     from nemo_amd import ops
     sc = full
