@@ -7,6 +7,9 @@ is one launch of the render kernel (pose -> R,T -> projection -> nearest-face ra
 barycentric interpolation) and is differentiable w.r.t. campos / theta / principal point through
 nemo_render_backward, which is what autograd through PyTorch3D provides in the reference.
 
+Several meshes at once (lists of vertices / faces / memory banks, reference :110-117, :133-143, :182-191):
+camera i renders mesh i (or the one camera renders every mesh); each mesh has its own handle and launch.
+
 Not supported (raise): the VoGE variant (needs the un-vendored VoGE package), blur_radius > 0,
 faces_per_pixel > 1, mode='nearest', off_set_mesh / deform_verts.
 """
@@ -22,6 +25,9 @@ def MeshInterpolateModule(*args, **kwargs):
     rasterizer = kwargs.get("rasterizer", args[3] if len(args) > 3 else None)
     if not isinstance(rasterizer, MeshRasterizer):
         raise NotImplementedError("only the mesh rasteriser variant exists here (the VoGE renderer is not available)")
+    vertices = kwargs.get("vertices", args[0] if args else None)
+    if isinstance(vertices, (list, tuple)):
+        return MeshInterpolateModuleMeshes(*args, **kwargs)
     return MeshInterpolateModuleMesh(*args, **kwargs)
 
 
@@ -52,7 +58,7 @@ class MeshInterpolateModuleMesh(nn.Module):
     def __init__(self, vertices, faces, memory_bank, rasterizer, post_process=None, off_set_mesh=False, **kwargs):
         super().__init__()
         if isinstance(vertices, (list, tuple)):
-            raise NotImplementedError("one mesh per module: build one MeshInterpolateModule per category mesh")
+            raise ValueError("a list of meshes is taken by MeshInterpolateModule(...) / MeshInterpolateModuleMeshes")
         if off_set_mesh:
             raise NotImplementedError("off_set_mesh / deform_verts is not supported")
         self.n_mesh = 1
@@ -132,6 +138,16 @@ class MeshInterpolateModuleMesh(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, campos, theta, blur_radius=0, deform_verts=None, mode="bilinear", **kwargs):
+        campos = campos.reshape(-1, 3)
+        theta = theta.reshape(-1)
+        if theta.numel() == 1 and campos.shape[0] > 1:
+            theta = theta.expand(campos.shape[0])
+        out = self._render(campos, theta, self._principal_arg(campos.shape[0]), blur_radius, deform_verts, mode)
+        if self.post_process is not None:
+            out = self.post_process(out)
+        return out
+
+    def _render(self, campos, theta, principal, blur_radius=0, deform_verts=None, mode="bilinear"):
         if self.mesh is None:
             raise RuntimeError("call .to(device) / .cuda() first: MeshInterpolateModule renders on the GPU only")
         if blur_radius not in (0, 0.0):
@@ -140,20 +156,11 @@ class MeshInterpolateModuleMesh(nn.Module):
             raise NotImplementedError("only mode='bilinear' is supported")
         if deform_verts is not None:
             raise NotImplementedError("deform_verts is not supported")
-        campos = campos.reshape(-1, 3)
-        theta = theta.reshape(-1)
-        if theta.numel() == 1 and campos.shape[0] > 1:
-            theta = theta.expand(campos.shape[0])
-        principal = self._principal_arg(campos.shape[0])
         needs_grad = torch.is_grad_enabled() and (campos.requires_grad or theta.requires_grad or (
             principal is not None and principal.requires_grad))
         if needs_grad:
-            out = _RenderFn.apply(campos, theta, principal, self)
-        else:
-            out = ops.render(self.mesh, self.camera(), campos, theta, principal, maps=True)["maps"]
-        if self.post_process is not None:
-            out = self.post_process(out)
-        return out
+            return _RenderFn.apply(campos, theta, principal, self)
+        return ops.render(self.mesh, self.camera(), campos, theta, principal, maps=True)["maps"]
 
     def rasterize(self, campos, theta):
         """Fragments of the same rasterisation: pix_to_face [n,H,W] int64 (packed index i*F + f as
@@ -165,3 +172,72 @@ class MeshInterpolateModuleMesh(nn.Module):
         offs = (torch.arange(campos.shape[0], device=p2f.device) * self.mesh.F)[:, None, None]
         return dict(pix_to_face=torch.where(p2f >= 0, p2f + offs, p2f), bary_coords=out["bary"], zbuf=out["zbuf"],
                     pix_to_face_local=out["pix_to_face"])
+
+
+class MeshInterpolateModuleMeshes(nn.Module):
+    """Several meshes in one module (reference mesh_interpolate_module.py:110-117, :182-191): forward with as many
+    cameras as meshes renders mesh i from camera i, with one camera every mesh from that camera; the result is
+    [n_mesh, C, H, W].  Every mesh is a single-mesh module of its own (own handle, own launch) sharing the
+    rasteriser; `parts[i]` is what a solver takes for category i."""
+
+    def __init__(self, vertices, faces, memory_bank, rasterizer, post_process=None, off_set_mesh=False, **kwargs):
+        super().__init__()
+        if not (isinstance(faces, (list, tuple)) and isinstance(memory_bank, (list, tuple))) or \
+                not (len(vertices) == len(faces) == len(memory_bank)) or len(vertices) == 0:
+            raise ValueError("vertices, faces and memory_bank must be lists of the same (non-zero) length")
+        self.n_mesh = len(vertices)
+        self.parts = nn.ModuleList([MeshInterpolateModuleMesh(v, f, m, rasterizer, post_process=None, off_set_mesh=off_set_mesh)
+                                    for v, f, m in zip(vertices, faces, memory_bank)])
+        self.rasterizer = rasterizer
+        self.post_process = post_process
+        self.off_set_mesh = off_set_mesh
+
+    @property
+    def faces(self):
+        return [p.faces for p in self.parts]
+
+    @property
+    def face_memory(self):
+        """[sum F, 3, C]: the meshes' face memories back to back, as the reference keeps them."""
+        return torch.cat([p.face_memory for p in self.parts], dim=0)
+
+    def update_memory(self, memory_bank, faces=None):
+        if not isinstance(memory_bank, (list, tuple)) or len(memory_bank) != self.n_mesh:
+            raise ValueError(f"memory_bank must be a list of {self.n_mesh} banks")
+        for i, p in enumerate(self.parts):
+            p.update_memory(memory_bank[i], None if faces is None else faces[i])
+
+    def to(self, *args, **kwargs):
+        for p in self.parts:
+            p.to(*args, **kwargs)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda") if device is None else device)
+
+    def update_rasterizer(self, rasterizer):
+        self.rasterizer = rasterizer
+        for p in self.parts:
+            p.update_rasterizer(rasterizer)
+
+    def camera(self):
+        return self.parts[0].camera()
+
+    def forward(self, campos, theta, blur_radius=0, deform_verts=None, mode="bilinear", **kwargs):
+        campos = campos.reshape(-1, 3)
+        theta = theta.reshape(-1)
+        n_cam = campos.shape[0]
+        if n_cam not in (1, self.n_mesh):
+            raise ValueError(f"{n_cam} cameras for {self.n_mesh} meshes")
+        if theta.numel() == 1 and n_cam > 1:
+            theta = theta.expand(n_cam)
+        pp = self.parts[0]._principal_arg(n_cam)
+        outs = []
+        for i, p in enumerate(self.parts):
+            j = i if n_cam > 1 else 0
+            pi = None if pp is None else (pp[j:j + 1] if pp.shape[0] > 1 else pp)
+            outs.append(p._render(campos[j:j + 1], theta[j:j + 1], pi, blur_radius, deform_verts, mode))
+        out = torch.cat(outs, dim=0)
+        if self.post_process is not None:
+            out = self.post_process(out)
+        return out

@@ -127,6 +127,45 @@ def test_largest_maps_and_size_limits(gpu):
             ops.project_keypoints(big.mod.mesh, cam, campos[:1].to(gpu), theta[:1].to(gpu))
 
 
+def test_module_with_several_meshes(small):
+    """A module holding several meshes: camera i renders mesh i (one camera renders every mesh); each map equals
+    the single-mesh module's, which is held to the oracle; gradients reach the poses of every mesh."""
+    import nemo_amd
+    from nemo_amd.utils import meshelize
+    sc = small
+    vb_, fb_ = meshelize((-0.2, 0.2), (-0.35, 0.35), (-0.25, 0.25), 150)
+    vb, fb = torch.from_numpy(np.asarray(vb_, dtype=np.float32)), torch.from_numpy(np.asarray(fb_)).long()
+    memb, _ = R.synthetic_bank(vb.shape[0], sc.C, n_clutter=4, seed=9)
+    va, fa = torch.as_tensor(sc.verts), torch.as_tensor(sc.faces).long()
+    multi = nemo_amd.MeshInterpolateModule([va, vb], [fa, fb], [sc.mem, memb], rasterizer=sc.mod.rasterizer).to(sc.device)
+    assert multi.n_mesh == 2 and multi.face_memory.shape[0] == fa.shape[0] + fb.shape[0]
+    single_b = nemo_amd.MeshInterpolateModule(vb, fb, memb, rasterizer=sc.mod.rasterizer).to(sc.device)
+    campos, theta = random_poses(2, seed=21)
+    out = multi(campos.to(sc.device), theta.to(sc.device))
+    assert tuple(out.shape) == (2, sc.C, sc.H, sc.W)
+    assert torch.equal(out[0:1], sc.mod(campos[0:1].to(sc.device), theta[0:1].to(sc.device)))
+    assert torch.equal(out[1:2], single_b(campos[1:2].to(sc.device), theta[1:2].to(sc.device)))
+    refb = R.MeshInterpolateModuleRef(vb.numpy(), fb.numpy(), memb, sc.cam)
+    assert rel_err(out[1:2], refb(campos[1:2], theta[1:2])) < REL
+    one = multi(campos[0:1].to(sc.device), theta[0:1].to(sc.device))            # one camera, every mesh
+    assert torch.equal(one[0:1], out[0:1]) and torch.equal(one[1:2], single_b(campos[0:1].to(sc.device), theta[0:1].to(sc.device)))
+    with pytest.raises(ValueError):
+        multi(torch.cat([campos, campos[:1]]).to(sc.device), torch.zeros(3, device=sc.device))
+    # autograd through both meshes
+    C = campos.to(sc.device).requires_grad_(True)
+    th = theta.to(sc.device).requires_grad_(True)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(sc.device)
+    (multi(C, th) * w).sum().backward()
+    Cb = campos[1:2].to(sc.device).requires_grad_(True)
+    thb = theta[1:2].to(sc.device).requires_grad_(True)
+    (single_b(Cb, thb) * w[1:2]).sum().backward()
+    assert torch.equal(C.grad[1:2], Cb.grad) and torch.equal(th.grad[1:2], thb.grad) and float(C.grad[0].abs().sum()) > 0
+    # new banks
+    multi.update_memory([sc.mem * 2.0, memb])
+    assert rel_err(multi(campos.to(sc.device), theta.to(sc.device))[0:1], 2.0 * out[0:1]) < 1e-6
+    multi.update_memory([sc.mem, memb])
+
+
 def test_clutter_score(full):
     from nemo_amd import ops
     sc = full
