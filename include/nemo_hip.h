@@ -237,10 +237,13 @@ int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stre
  * feature-map pixels, out_kp [n,V,2] = (y, x) (clamped to the map when restrict_to_boundary != 0), and
  * out_vis [n,V] u8 = 1 where the distance map (per-vertex distance to cam_loc = -inverse(R) T, interpolated
  * over the rasterised faces) read at the nearest pixel equals the vertex's own distance within dist_thr.
- * principal [n,2] in feature-map pixels or NULL.  The distance map is never materialised. */
+ * principal [n,2] in feature-map pixels or NULL.  rt [n,12] or NULL: the caller's own R (row-major, PyTorch3D
+ * convention X_view = X R + T) followed by T per pose, used instead of campos / theta (the R=, T= keyword
+ * arguments of PackedRaster.__call__, :127-129); campos and theta may then be NULL.  The distance map is never
+ * materialised. */
 int nemo_project_keypoints(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
-                           const float* principal, int32_t n, float dist_thr, int32_t restrict_to_boundary,
-                           float* out_kp, uint8_t* out_vis, void* stream);
+                           const float* rt, const float* principal, int32_t n, float dist_thr,
+                           int32_t restrict_to_boundary, float* out_kp, uint8_t* out_vis, void* stream);
 
 /* ---- feature-bank bookkeeping of multi-object batches (the reference's CuNeMo extension) ----
  * An image n holds up to M objects: sample_indexs[n,i] = mesh index of object i (-1: none); its K padded

@@ -81,7 +81,7 @@ def load():
                                     C.POINTER(NemoAdam), f32p, f32p, vp]
     lib.nemo_align_maps.argtypes = [f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, vp]
     lib.nemo_spherical_angles.argtypes = [f32p, i32, f32p, vp]
-    lib.nemo_project_keypoints.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, C.c_float, i32, f32p, vp, vp]
+    lib.nemo_project_keypoints.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, f32p, i32, C.c_float, i32, f32p, vp, vp]
     lib.nemo_gather_features.argtypes = [f32p, f32p, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32p, f32p, vp, vp]
     lib.nemo_gather_features_backward.argtypes = [f32p, f32p, f32p, f32p, vp, i32, i32, i32, f32p, f32p, vp]
     lib.nemo_gather_idx.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -1390,6 +1390,7 @@ extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B
 struct KeypointVisArgs {
     RasterCtx rc;
     const float* campos; const float* theta; const float* principal;
+    const float* rt;             // optional [n, 12]: R (row-major, X_view = X R + T) and T given by the caller instead of campos / theta
     float def_px, def_py, focal, dist_thr;
     int clamp_to_image;
     float* out_kp; uint8_t* out_vis;
@@ -1409,8 +1410,14 @@ __global__ __launch_bounds__(kRasterThreads) void keypoint_vis_kernel(KeypointVi
     raster_prologue(a.rc, s);
     const float px = a.principal ? a.principal[2 * n] : a.def_px, py = a.principal ? a.principal[2 * n + 1] : a.def_py;
     if (threadIdx.x == 0) {
-        float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
-        pose_setup(a.rc.cc, C, a.theta[n], px, py, s.pc);
+        if (a.rt) {
+            for (int i = 0; i < 9; ++i) s.pc->R[i] = a.rt[12 * (size_t)n + i];
+            for (int i = 0; i < 3; ++i) s.pc->T[i] = a.rt[12 * (size_t)n + 9 + i];
+            s.pc->bx = (a.rc.cc.half_w - px) / a.rc.cc.s; s.pc->by = (a.rc.cc.half_h - py) / a.rc.cc.s;
+        } else {
+            float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
+            pose_setup(a.rc.cc, C, a.theta[n], px, py, s.pc);
+        }
     }
     __syncthreads();
     project_vertices(a.rc, s);
@@ -1461,10 +1468,11 @@ __global__ __launch_bounds__(kRasterThreads) void keypoint_vis_kernel(KeypointVi
 }
 
 extern "C" int nemo_project_keypoints(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
-                                      const float* principal, int32_t n, float dist_thr, int32_t restrict_to_boundary,
-                                      float* out_kp, uint8_t* out_vis, void* stream) {
+                                      const float* rt, const float* principal, int32_t n, float dist_thr,
+                                      int32_t restrict_to_boundary, float* out_kp, uint8_t* out_vis, void* stream) {
     if (n == 0) return NEMO_OK;
-    if (!m || !campos || !theta || !out_kp || !out_vis || n < 0) return fail(NEMO_ERR_INVALID, "nemo_project_keypoints: bad argument");
+    if (!m || (!rt && (!campos || !theta)) || !out_kp || !out_vis || n < 0)
+        return fail(NEMO_ERR_INVALID, "nemo_project_keypoints: bad argument");
     if (check_cam(cam)) return NEMO_ERR_INVALID;
     KeypointVisArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces; a.rc.V = m->V; a.rc.F = m->F;
@@ -1474,7 +1482,7 @@ extern "C" int nemo_project_keypoints(nemo_mesh_t m, const nemo_camera* cam, con
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_layout(cam->H, cam->W, m->V, m->F, kRasterThreads, &a.rc.L);
     if (rcode) return rcode;
-    a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
+    a.campos = campos; a.theta = theta; a.rt = rt; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
     a.focal = cam->focal; a.dist_thr = dist_thr; a.clamp_to_image = restrict_to_boundary != 0;
     a.out_kp = out_kp; a.out_vis = out_vis;
     auto kern = a.rc.L.faces >= 0 ? keypoint_vis_kernel<true> : keypoint_vis_kernel<false>;

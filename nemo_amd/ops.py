@@ -111,15 +111,29 @@ def project(mesh, cam, campos, theta, principal=None):
     return rt, proj
 
 
-def project_keypoints(mesh, cam, campos, theta, principal=None, dist_thr=1e-3, restrict_to_boundary=True):
-    """Training-side annotation: -> (kp [n,V,2] = (y, x) feature-map pixels, vis [n,V] bool)."""
+def project_keypoints(mesh, cam, campos, theta, principal=None, dist_thr=1e-3, restrict_to_boundary=True, R=None, T=None):
+    """Training-side annotation: -> (kp [n,V,2] = (y, x) feature-map pixels, vis [n,V] bool).
+    With R [n,3,3] (X_view = X @ R + T) and T [n,3] the caller's own extrinsics replace campos / theta."""
     lib = _lib.load()
-    cp, th, pr, n = _pose_args(campos, theta, principal)
-    kp = torch.empty(n, mesh.V, 2, device=cp.device)
-    vis = torch.empty(n, mesh.V, dtype=torch.uint8, device=cp.device)
+    if (R is None) != (T is None):
+        raise ValueError("R and T go together")
+    if R is not None:
+        rt = torch.cat([f32c(R).reshape(-1, 9), f32c(T).reshape(-1, 3)], dim=1).contiguous()
+        n, dev, cp, th = rt.shape[0], rt.device, None, None
+        pr = None
+        if principal is not None:
+            pr = f32c(principal).reshape(-1, 2)
+            pr = pr.expand(n, 2).contiguous() if pr.shape[0] == 1 and n > 1 else pr
+            if pr.shape[0] != n:
+                raise ValueError(f"principal has {pr.shape[0]} rows for {n} cameras")
+    else:
+        cp, th, pr, n = _pose_args(campos, theta, principal)
+        rt, dev = None, cp.device
+    kp = torch.empty(n, mesh.V, 2, device=dev)
+    vis = torch.empty(n, mesh.V, dtype=torch.uint8, device=dev)
     cc = cam.c()
-    with torch.cuda.device(cp.device):
-        check(lib.nemo_project_keypoints(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, float(dist_thr),
+    with torch.cuda.device(dev):
+        check(lib.nemo_project_keypoints(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(rt), ptr(pr), n, float(dist_thr),
                                          1 if restrict_to_boundary else 0, ptr(kp), ptr(vis, torch.uint8), stream_ptr()),
               "nemo_project_keypoints")
     return kp, vis.bool()

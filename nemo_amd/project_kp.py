@@ -105,11 +105,21 @@ class PackedRaster:
         """-> (project_verts [b, Vmax, 2] as (y, x) in feature-map pixels, vis_mask [b, Vmax] bool).
         kwargs: principal [b, 2] in image pixels (divided by down_rate like the reference), restrict_to_boundary,
         dist_thr, func_of_mesh (+ indexs, transforms)."""
-        if "R" in kwargs or "T" in kwargs:
-            raise NotImplementedError("PackedRaster: pass azim / elev / dist / theta (explicit R, T are not supported)")
-        campos = camera_position_from_spherical_angles(dist, elev, azim, degrees=self.use_degree, device=self.device)
-        theta = torch.as_tensor(theta, dtype=torch.float32).reshape(-1).to(self.device)
-        n = campos.shape[0]
+        ext = None
+        if "R" in kwargs and "T" in kwargs:               # the caller's own extrinsics (reference :127-129)
+            ext = (kwargs["R"].float().to(self.device).reshape(-1, 3, 3), kwargs["T"].float().to(self.device).reshape(-1, 3))
+            campos = theta = None
+            n = ext[0].shape[0]
+        else:
+            campos = camera_position_from_spherical_angles(dist, elev, azim, degrees=self.use_degree, device=self.device)
+            theta = torch.as_tensor(theta, dtype=torch.float32).reshape(-1).to(self.device)
+            n = campos.shape[0]
+
+        def annotate(handle, rows=None):
+            sel = (lambda t: t) if rows is None else (lambda t: None if t is None else t[rows])
+            return ops.project_keypoints(handle, self.camera, sel(campos), sel(theta), sel(principal), dist_thr=dist_thr,
+                                         restrict_to_boundary=restrict, R=None if ext is None else sel(ext[0]),
+                                         T=None if ext is None else sel(ext[1]))
         principal = kwargs.get("principal", None)
         if principal is not None:
             principal = (principal.float().to(self.device) / self.down_rate).reshape(-1, 2)
@@ -122,8 +132,7 @@ class PackedRaster:
         name = getattr(func, "__name__", str(func))
         if name == "func_single":
             if len(self.handles) == 1:
-                return ops.project_keypoints(self.mesh, self.camera, campos, theta, principal, dist_thr=dist_thr,
-                                             restrict_to_boundary=restrict)
+                return annotate(self.mesh)
             if len(self.handles) != n:
                 raise ValueError(f"func_single: {len(self.handles)} meshes for {n} poses")
             per_pose = list(self.handles)
@@ -153,8 +162,7 @@ class PackedRaster:
             groups.setdefault(id(h), (h, []))[1].append(i)
         for h, rows in groups.values():
             r = torch.tensor(rows, device=self.device)
-            k_, v_ = ops.project_keypoints(h, self.camera, campos[r], theta[r], None if principal is None else principal[r],
-                                           dist_thr=dist_thr, restrict_to_boundary=restrict)
+            k_, v_ = annotate(h, r)
             kp[r, :h.V] = k_
             vis[r, :h.V] = v_
         if name == "func_multi_select":

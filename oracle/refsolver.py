@@ -278,11 +278,17 @@ def pixel_centers(H, W):
     return torch.from_numpy(xf), torch.from_numpy(yf)
 
 
-def project_verts(verts, campos, theta, cam, principal=None):
+def project_verts(verts, campos, theta, cam, principal=None, rt=None):
     """World verts [V,3] -> per camera view coords and NDC xy.  X_view = X @ R + T (row vectors);
     x_ndc = (a*X)/Z + bx with a = f/s, bx = (W/2 - px)/s, s = min(H,W)/2 (screen-space pinhole
-    x_s = f X/Z + px followed by the screen->NDC map of a non-square image); depth = Z_view."""
-    R, T = campos_to_R_T(campos, theta)
+    x_s = f X/Z + px followed by the screen->NDC map of a non-square image); depth = Z_view.
+    rt = (R [n,3,3], T [n,3]): the caller's extrinsics instead of campos / theta."""
+    if rt is not None:
+        R = [[rt[0][:, i, j] for j in range(3)] for i in range(3)]
+        T = [rt[1][:, j] for j in range(3)]
+        campos = rt[1]                                   # only its leading size is used below
+    else:
+        R, T = campos_to_R_T(campos, theta)
     X0, X1, X2 = verts[None, :, 0], verts[None, :, 1], verts[None, :, 2]
     Xv = [((X0 * R[0][j][:, None] + X1 * R[1][j][:, None]) + X2 * R[2][j][:, None]) + T[j][:, None]
           for j in range(3)]
@@ -351,12 +357,12 @@ def rasterize_naive(xn, yn, zv, faces, H, W, rows_per_chunk=8):
     return out
 
 
-def fragments(verts, faces, campos, theta, cam, principal=None):
+def fragments(verts, faces, campos, theta, cam, principal=None, rt=None):
     """Rasterise `n` cameras.  pix_to_face [n,H,W] (local face idx, -1 = background), bary
     [n,H,W,3] and zbuf [n,H,W] (differentiable w.r.t. campos/theta/principal; -1 on background)."""
-    xn, yn, zv, _ = project_verts(verts, campos, theta, cam, principal)
+    xn, yn, zv, _ = project_verts(verts, campos, theta, cam, principal, rt)
     p2f = rasterize_naive(xn.detach(), yn.detach(), zv.detach(), faces, cam.H, cam.W)
-    n = campos.shape[0]
+    n = xn.shape[0]
     xf, yf = pixel_centers(cam.H, cam.W)
     fsel = faces.long()[p2f.clamp(min=0)]                      # [n,H,W,3]
     ar = torch.arange(n)[:, None, None]
@@ -776,16 +782,16 @@ def synthetic_feature_map(inter, clutter, seed, noise=0.5):
 # --------------------------------------------------------------------------------------
 # training-side keypoint annotation (nemo/models/project_kp.py:175-247, one mesh per pose)
 # --------------------------------------------------------------------------------------
-def project_keypoints(verts, faces, campos, theta, cam, principal=None, restrict_to_boundary=True, dist_thr=1e-3):
+def project_keypoints(verts, faces, campos, theta, cam, principal=None, restrict_to_boundary=True, dist_thr=1e-3, rt=None):
     """get_one_standard (project_kp.py:175-247) with func_single: -> (project_verts [n,V,2] as (y, x) in
     feature-map pixels, vis_mask [n,V] bool, margin [n,V] = | |sampled - true| - dist_thr | for tests that
     want to skip vertices sitting on the threshold).  The PyTorch3D pinhole is restated as
     x_t = (f X + px Z) / Z (PerspectiveCameras(in_ndc=False).transform_points: K then divide by w)."""
-    n, V = campos.shape[0], verts.shape[0]
-    R, T = R_T_tensors(campos, theta)                      # X_view = X @ R + T
+    R, T = R_T_tensors(campos, theta) if rt is None else rt      # X_view = X @ R + T
+    n, V = R.shape[0], verts.shape[0]
     pr = torch.tensor([cam.principal], dtype=torch.float32).expand(n, 2) if principal is None else principal.float()
     cam_loc = -torch.matmul(torch.inverse(R), T[..., None])[:, :, 0]                       # :183
-    _, _, _, Xv = project_verts(verts, campos, theta, cam, principal)
+    _, _, _, Xv = project_verts(verts, campos, theta, cam, principal, rt)
     xt = (cam.focal * Xv[0] + pr[:, 0:1] * Xv[2]) / Xv[2]
     yt = (cam.focal * Xv[1] + pr[:, 1:2] * Xv[2]) / Xv[2]
     project = torch.stack([2 * pr[:, 1:2] - yt, 2 * pr[:, 0:1] - xt], dim=-1)            # :186-188, (y, x)
@@ -793,7 +799,7 @@ def project_keypoints(verts, faces, campos, theta, cam, principal=None, restrict
     if restrict_to_boundary:                                                               # :194-197
         project = torch.min(project, (size.unsqueeze(1) - 1) * torch.ones_like(project))
         project = torch.max(project, torch.zeros_like(project))
-    p2f, bary, _ = fragments(verts, faces, campos, theta, cam, principal)
+    p2f, bary, _ = fragments(verts, faces, campos, theta, cam, principal, rt)
     true_dist = (cam_loc[:, None] - verts[None]).pow(2).sum(-1).pow(.5)                   # [n,V] :201
     face_dist = true_dist[:, faces.long()]                                                # [n,F,3] :202
     depth = torch.zeros(n, cam.H, cam.W)

@@ -911,6 +911,34 @@ def _assert_keypoints_match(kp, vis, rkp, rvis, margin):
     assert float((vis.cpu() != rvis).float().mean()) < 0.01
 
 
+def test_packed_raster_with_explicit_extrinsics(small):
+    """R=, T= keyword arguments: the look-at extrinsics passed explicitly give exactly the azim / elev / dist /
+    theta answer; a general rigid motion (object off the optical axis, not a look-at pose) follows the oracle."""
+    from nemo_amd.project_kp import PackedRaster
+    sc = small
+    cfgs = dict(type="near", image_size=(sc.H * 8, sc.W * 8), down_rate=8, focal_length=sc.cam.focal * 8)
+    pr = PackedRaster(cfgs, (sc.verts, sc.faces), device=sc.device)
+    n = 4
+    g = torch.Generator().manual_seed(31)
+    azim, elev = torch.rand(n, generator=g) * 2 * math.pi, (torch.rand(n, generator=g) - 0.3) * 1.2
+    theta, dist = (torch.rand(n, generator=g) - 0.5) * 0.6, torch.full((n,), 5.0)
+    campos = R.camera_position_from_spherical_angles(dist, elev, azim)
+    Rm, T = R.R_T_tensors(campos, theta)
+    k0, v0 = pr(azim, elev, dist, theta, dist_thr=0.05)
+    k1, v1 = pr(None, None, None, None, R=Rm, T=T, dist_thr=0.05)
+    assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    T2 = T + torch.tensor([[0.4, -0.2, 0.5]])               # shifted off the axis and pushed back
+    verts = torch.as_tensor(sc.verts)
+    kp, vis = pr(None, None, None, None, R=Rm, T=T2, dist_thr=0.05, restrict_to_boundary=False)
+    rkp, rvis, margin = R.project_keypoints(verts, torch.as_tensor(sc.faces), None, None, sc.cam, restrict_to_boundary=False,
+                                            dist_thr=0.05, rt=(Rm, T2))
+    _assert_keypoints_match(kp, vis, rkp, rvis, margin)
+    assert float((kp.cpu() - k0.cpu()).abs().max()) > 5.0
+    with pytest.raises(ValueError):
+        from nemo_amd import ops
+        ops.project_keypoints(pr.mesh, pr.camera, None, None, R=Rm.to(sc.device))
+
+
 def test_packed_raster_mesh_per_pose_and_scenes(small):
     """func_reselect (a mesh per pose out of several) and func_multi_select (a scene of moved meshes per pose,
     the objects occluding each other): every pose equals the oracle's annotation of its own mesh / scene; outputs
