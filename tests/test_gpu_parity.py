@@ -396,6 +396,58 @@ def test_global_batch_scaling(small):
     assert torch.equal(got[0], multi[0]) and torch.equal(got[2], multi[2]) and torch.isfinite(hist[0]).all()
 
 
+def test_full_size_batch_properties(full):
+    """BASELINE size (64 images of 80 x 100 x 128, V=1118, 144-pose grid, 300 steps), where the oracle would take
+    minutes: properties that do not depend on an expected value.  An image's grid losses, arg-min and 300-step
+    result do not depend on its position in the batch (bit for bit); the similarity table is linear in the
+    feature map; the solved poses recover the poses the synthetic images were rendered at."""
+    import nemo_amd
+    from nemo_amd import ops
+    from nemo_amd.utils import default_pose3d_config
+    sc = full
+    dev = sc.device
+    B = 64
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    g = torch.Generator().manual_seed(5)
+    u = torch.rand(B, 3, generator=g)
+    gaz, gel, gth = u[:, 0] * 2 * math.pi, -math.pi / 6 + u[:, 1] * math.pi / 2, -math.pi / 6 + u[:, 2] * math.pi / 3
+    campos = R.camera_position_from_spherical_angles(torch.full((B,), 5.0), gel, gaz).to(dev)
+    with torch.no_grad():
+        fm = sc.mod(campos, gth.float().to(dev))
+    clutter = sc.clutter.to(dev)
+    bg = (fm.abs().sum(dim=1, keepdim=True) == 0).float()
+    noise = torch.randn(fm.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+    fm = torch.nn.functional.normalize(fm + bg * clutter.view(1, -1, 1, 1) + 0.5 / math.sqrt(sc.C) * noise, dim=1).contiguous()
+
+    def run(x):
+        clu = ops.clutter_score(x, clutter)
+        loss, amin, mn = ops.grid_score(None, x, clu, packed=maps._nemo_packed_grid)
+        tab = ops.similarity_table(sc.mod.mesh, x)
+        pose, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu, cs[amin.long()], ths[amin.long()], global_batch=B, steps=300,
+                            lr_every=100)
+        return clu, loss, amin, pose, tab
+
+    clu, loss, amin, pose, tab = run(fm)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).to(dev)
+    clu_p, loss_p, amin_p, pose_p, _ = run(fm[perm].contiguous())
+    assert torch.equal(clu_p, clu[perm]) and torch.equal(loss_p, loss[perm]) and torch.equal(amin_p, amin[perm])
+    assert torch.equal(pose_p, pose[perm])
+    assert torch.equal(amin.long(), loss.argmin(dim=1))
+    # linearity of the table (its two-piece f16 operands are rescaled per call, so to rounding, not to the bit)
+    a, b = fm[:2], fm[2:4]
+    t_ab = ops.similarity_table(sc.mod.mesh, (0.5 * a + 0.25 * b).contiguous())
+    assert rel_err(t_ab, 0.5 * tab[:2] + 0.25 * tab[2:4]) < 1e-6
+    # the answers: distance, elevation, azimuth, theta against the poses the images were rendered at
+    sph = ops.spherical_angles(pose[:, 0:3]).cpu()
+    errs = []
+    for i in range(B):
+        errs.append(R.pose_error(dict(azimuth=float(gaz[i]), elevation=float(gel[i]), theta=float(gth[i])),
+                                 dict(azimuth=float(sph[i, 2]), elevation=float(sph[i, 1]), theta=float(pose[i, 3]))) * 180 / math.pi)
+    errs.sort()
+    assert errs[B // 2] < 0.5 and errs[int(B * 0.9)] < 2.0, errs
+
+
 # ---- committed golden fixtures (tests/golden, made by oracle/gen_golden.py) -----------------------------
 import os
 
