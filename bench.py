@@ -96,7 +96,7 @@ def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=EPOCHS
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 2: 64)")
     ap.add_argument("--in-flight", type=int, default=8,
