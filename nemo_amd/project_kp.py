@@ -115,11 +115,6 @@ class PackedRaster:
             theta = torch.as_tensor(theta, dtype=torch.float32).reshape(-1).to(self.device)
             n = campos.shape[0]
 
-        def annotate(handle, rows=None):
-            sel = (lambda t: t) if rows is None else (lambda t: None if t is None else t[rows])
-            return ops.project_keypoints(handle, self.camera, sel(campos), sel(theta), sel(principal), dist_thr=dist_thr,
-                                         restrict_to_boundary=restrict, R=None if ext is None else sel(ext[0]),
-                                         T=None if ext is None else sel(ext[1]))
         principal = kwargs.get("principal", None)
         if principal is not None:
             principal = (principal.float().to(self.device) / self.down_rate).reshape(-1, 2)
@@ -127,6 +122,12 @@ class PackedRaster:
                 principal = principal.expand(n, 2)
         dist_thr = kwargs.get("dist_thr", self.kwargs.get("dist_thr", 1e-3))
         restrict = kwargs.get("restrict_to_boundary", self.kwargs.get("restrict_to_boundary", True))
+
+        def annotate(handle, rows=None):
+            sel = (lambda t: t) if rows is None else (lambda t: None if t is None else t[rows])
+            return ops.project_keypoints(handle, self.camera, sel(campos), sel(theta), sel(principal), dist_thr=dist_thr,
+                                         restrict_to_boundary=restrict, R=None if ext is None else sel(ext[0]),
+                                         T=None if ext is None else sel(ext[1]))
 
         func = kwargs.get("func_of_mesh", None) or func_single
         name = getattr(func, "__name__", str(func))
