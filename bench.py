@@ -308,7 +308,7 @@ def main():
                                  "so frac > 1 means it beats the streaming roofline; see DESIGN.md"},
             "front_kernel_rooflines": other,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(mod, mem, clutter, v, f, fm_g[0], pre, cs, ths)
         print(json.dumps(out))
     if world > 1:
