@@ -305,7 +305,7 @@ def main():
                          "note": "achieved = 300 steps x hypotheses per launch x 4.128 MB (one read of the image's feature map + clutter "
                                  "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
                                  "kernel reads a precomputed vertex x pixel similarity table instead (3 floats per covered pixel), "
-                                 "so frac > 1 means it beats the streaming roofline; see DESIGN.md"},
+                                 "so frac > 1 means it beats the streaming roofline"},
             "front_kernel_rooflines": other,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
