@@ -228,6 +228,30 @@ int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table
                     int32_t optimize_translation, float translation_scale, const nemo_adam* opt,
                     float* out_pose, float* out_loss_hist, void* stream);
 
+/* ---- partial similarity tables (no counterpart in the reference, which scores every pixel against the
+ * rendered map; an optimisation of nemo_similarity_table + nemo_solve for one hypothesis per image) ----
+ * The optimisation loop of batch_solve_pose.py:306-338 reads table entry (vertex, pixel) only where a face of
+ * that vertex covers the pixel.  nemo_table_ranges projects every 32-vertex block at the starting pose and
+ * returns, per image and block, the first and last 128-pixel tile of the rows the block falls in, widened by
+ * margin_rows: out_ranges [n][nemo_table_range_blocks(mesh)][2] int32.  nemo_similarity_table_partial computes
+ * only those (tile, block) products (the rest of `table` is left as it was); with only_flagged [B] it instead
+ * computes the complete table of the images whose entry is non-zero.  nemo_solve_partial is nemo_solve for
+ * n_hyp == n_img with such a table: a hypothesis whose faces need a tile outside its ranges sets
+ * miss_flags[h] = 1 (the caller zeroes the array; the hypothesis's output row is then void); with only_flagged
+ * [n_img] only the hypotheses with a non-zero entry run.  A caller repeats flagged images as
+ *   nemo_similarity_table_partial(..., NULL, miss_flags, table); nemo_solve_partial(..., NULL, NULL, miss_flags, ...)
+ * after which every row equals what nemo_similarity_table + nemo_solve give, bit for bit. */
+int32_t nemo_table_range_blocks(nemo_mesh_t mesh);
+int nemo_table_ranges(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
+                      const float* principal, int32_t n, int32_t margin_rows, int32_t* out_ranges, void* stream);
+int nemo_similarity_table_partial(nemo_mesh_t mesh, const float* feat, int32_t B, int32_t HW, const int32_t* table_ranges,
+                                  const int32_t* only_flagged, float* table, void* stream);
+int nemo_solve_partial(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, const float* clutter_score,
+                       const float* init_campos, const float* init_theta, const float* init_principal,
+                       const int32_t* score_boxes, int32_t n_img, int32_t global_batch, int32_t dof,
+                       const nemo_adam* opt, const int32_t* table_ranges, int32_t* miss_flags,
+                       const int32_t* only_flagged, float* out_pose, float* out_loss_hist, void* stream);
+
 /* camera_position_to_spherical_angle (nemo/utils/mesh.py:50-56) on device:
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */
 int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream);

@@ -174,7 +174,9 @@ void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_
 int launch_grid_mfma_recentred(const void* packed, const float* feat_src, const float* clu, int N, int B, int C, int Bsrc, int h1, int w1,
                                int h0, int w0, int border, const float* dist_src, const float* dist_tgt, const float* p_src,
                                const float* p_tgt, void* featp, float* partial, hipStream_t st);
-int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
+int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, const int32_t* ranges,
+                       const int32_t* only, hipStream_t st);
+int split_bank_blocks(int V);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
@@ -876,6 +878,9 @@ struct SolveArgs {
     const float* table; const float* clu; const int32_t* hyp_to_image;
     const float* init_campos; const float* init_theta; const float* init_principal;
     const int32_t* score_boxes;
+    const int32_t* ranges; int nvb;      // partial similarity table: [n_img][nvb][2] first / last pixel tile per 32-vertex block, or null
+    int32_t* miss;                       // [n_hyp]: set to 1 when the hypothesis needed a tile outside the ranges (its result is then void)
+    const int32_t* only;                 // [n_hyp] or null: hypotheses with a zero entry are left alone
     float def_px, def_py;
     float tscale, inv_tscale;    // warp mode: the reference's translation_scale (flow units per pixel) and its inverse
     int n_img; float inv_norm; int dof;
@@ -896,6 +901,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     const int h = blockIdx.x, tid = threadIdx.x;
     const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
     const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
+    if (a.only && a.only[h] == 0) return;
     if ((unsigned)img >= (unsigned)a.n_img) {      // a hypothesis that names no image: NaN row, nothing read
         if (tid < 8) a.out_pose[(size_t)h * 8 + tid] = __builtin_nanf("");
         if (a.out_hist)
@@ -906,6 +912,15 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     const int vg_n = (V + 3) >> 2;
     const float* clu = a.clu + (size_t)img * HW;
     solve_prologue(a.rc, s);
+    if (a.ranges) {
+        for (int k = tid; k < a.nvb; k += blockDim.x) {
+            const int32_t* r = a.ranges + ((size_t)img * a.nvb + k) * 2;
+            s.need[k] = (unsigned)min(max(r[0], 0), 0xFFFF) | (unsigned)min(max(r[1], 0), 0xFFFF) << 16;
+        }
+        s.miss = a.miss + h;
+    } else {
+        s.need = nullptr;
+    }
 
     // Adam's per-step constants (torch single-tensor path: bias corrections and step size in double, then
     // cast): step_size = -lr_k / (1 - beta1^(k+1)), sqrt(1 - beta2^(k+1)); lr_k follows the exponential schedule.
@@ -1208,11 +1223,11 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
-extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
-                          const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
-                          const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
-                          int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
-                          void* stream) {
+static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+                      const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
+                      const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
+                      int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
+                      const int32_t* table_ranges, int32_t* miss_flags, const int32_t* only, void* stream) {
     if (n_hyp == 0) return NEMO_OK;
     if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
         return fail(NEMO_ERR_INVALID, "nemo_solve: bad argument");
@@ -1238,11 +1253,37 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
     a.out_pose = out_pose; a.out_hist = out_hist;
     a.tscale = 1.0f; a.inv_tscale = 0.0f;
+    a.ranges = table_ranges; a.miss = miss_flags; a.only = only; a.nvb = nemo::split_bank_blocks(m->V);
+    if (table_ranges) {
+        if (!miss_flags) return fail(NEMO_ERR_INVALID, "nemo_solve_partial: table_ranges need miss_flags");
+        if (hyp_to_image) return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_partial: one hypothesis per image (no hyp_to_image)");
+        if (a.nvb > kNeedBlocks || !m->bank_frag)
+            return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_partial: at most %d vertices and a channel count of 16, 32, 64 or 128", 32 * kNeedBlocks);
+    }
     auto kern = a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>;
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
+}
+
+extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+                          const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
+                          const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
+                          int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
+                          void* stream) {
+    return solve_impl(m, cam, table, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
+                      global_batch, dof, opt, out_pose, out_hist, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int nemo_solve_partial(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+                                  const float* init_campos, const float* init_theta, const float* init_principal,
+                                  const int32_t* score_boxes, int32_t n_img, int32_t global_batch, int32_t dof,
+                                  const nemo_adam* opt, const int32_t* table_ranges, int32_t* miss_flags,
+                                  const int32_t* only_flagged, float* out_pose, float* out_hist, void* stream) {
+    if (!table_ranges && !only_flagged) return fail(NEMO_ERR_INVALID, "nemo_solve_partial: table_ranges or only_flagged");
+    return solve_impl(m, cam, table, clu, nullptr, init_campos, init_theta, init_principal, score_boxes, n_img, n_img, global_batch,
+                      dof, opt, out_pose, out_hist, table_ranges, miss_flags, only_flagged, stream);
 }
 
 // Refinement of the keypoint-initialised solver (solve_pose.py:220-324): every proposal of an image is one
@@ -1266,6 +1307,7 @@ extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const floa
     int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
     if (rcode) return rcode;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
+    a.ranges = nullptr; a.miss = nullptr; a.only = nullptr; a.nvb = 0;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_flow;
     a.score_boxes = nullptr;
     a.def_px = cam->px; a.def_py = cam->py;
@@ -1368,10 +1410,88 @@ extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B
     if (B == 0) return NEMO_OK;
     if (!m || !feat || !table || B < 0 || HW <= 0) return fail(NEMO_ERR_INVALID, "nemo_similarity_table: bad argument");
     if (!m->memory_t) return fail(NEMO_ERR_STATE, "nemo_similarity_table: mesh has no vertex memory");
-    const int rc = m->bank_frag ? nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, (hipStream_t)stream)
+    const int rc = m->bank_frag ? nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, nullptr, nullptr, (hipStream_t)stream)
                                 : nemo::launch_table_gemm(m->memory_t, feat, table, m->V, m->C, HW, B, (hipStream_t)stream);
     if (rc)
         return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table: too many tiles for one launch");
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// partial similarity tables
+// ------------------------------------------------------------------------------------------
+// The optimisation loop reads a table entry (vertex, pixel) only where a face of that vertex covers the pixel
+// during some step.  For every image and 32-vertex block, table_ranges_kernel projects the block's vertices at
+// the starting pose and returns the 128-pixel tiles of the rows they fall in, widened by margin_rows: the table
+// kernel computes only those (tile, block) products, and the solve kernel raises a flag for a hypothesis whose
+// faces leave the ranges (raster_direct), which the caller then repeats on a complete table.
+struct RangeArgs {
+    const float* verts; int V, nvb; CamConst cc;
+    const float* campos; const float* theta; const float* principal;
+    float def_px, def_py, focal; int margin;
+    int32_t* out;
+};
+
+__global__ __launch_bounds__(256) void table_ranges_kernel(RangeArgs a) {
+    __shared__ PoseCam pc;
+    __shared__ int lo[kNeedBlocks], hi[kNeedBlocks];
+    const int n = blockIdx.x, H = a.cc.H, W = a.cc.W;
+    const float py = a.principal ? a.principal[2 * n + 1] : a.def_py;
+    if (threadIdx.x == 0) {
+        float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
+        pose_setup(a.cc, C, a.theta[n], a.principal ? a.principal[2 * n] : a.def_px, py, &pc);
+    }
+    for (int k = threadIdx.x; k < a.nvb; k += blockDim.x) { lo[k] = H; hi[k] = -1; }
+    __syncthreads();
+    for (int v = threadIdx.x; v < a.V; v += blockDim.x) {
+        float Xv[3], xn, yn;
+        project_vertex(a.cc, pc.R, pc.T, pc.bx, pc.by, a.verts[3 * v], a.verts[3 * v + 1], a.verts[3 * v + 2], Xv, &xn, &yn);
+        int r0 = 0, r1 = H - 1;                              // a vertex at or behind the camera plane: every row
+        if (Xv[2] > 1e-3f) {
+            const float row = py - a.focal * Xv[1] / Xv[2];  // feature-map row of the projected vertex
+            if (row == row) {
+                r0 = (int)fminf(fmaxf(floorf(row) - (float)a.margin, 0.0f), (float)(H - 1));
+                r1 = (int)fminf(fmaxf(floorf(row) + 1.0f + (float)a.margin, 0.0f), (float)(H - 1));
+            }
+        }
+        atomicMin(&lo[v >> 5], r0);
+        atomicMax(&hi[v >> 5], r1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < a.nvb; k += blockDim.x) {
+        int32_t* o = a.out + ((size_t)n * a.nvb + k) * 2;
+        if (hi[k] < lo[k]) { o[0] = 1; o[1] = 0; }           // a block of padding rows: never read
+        else { o[0] = (lo[k] * W) >> 7; o[1] = (hi[k] * W + W - 1) >> 7; }
+    }
+}
+
+extern "C" int32_t nemo_table_range_blocks(nemo_mesh_t m) { return m ? nemo::split_bank_blocks(m->V) : 0; }
+
+extern "C" int nemo_table_ranges(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                 const float* principal, int32_t n, int32_t margin_rows, int32_t* out_ranges, void* stream) {
+    if (n == 0) return NEMO_OK;
+    if (!m || !campos || !theta || !out_ranges || n < 0 || margin_rows < 0) return fail(NEMO_ERR_INVALID, "nemo_table_ranges: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    RangeArgs a;
+    a.verts = m->verts; a.V = m->V; a.nvb = nemo::split_bank_blocks(m->V);
+    if (a.nvb > kNeedBlocks) return fail(NEMO_ERR_UNSUPPORTED, "nemo_table_ranges: at most %d vertices", 32 * kNeedBlocks);
+    a.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py; a.focal = cam->focal;
+    a.margin = margin_rows; a.out = out_ranges;
+    hipLaunchKernelGGL(table_ranges_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" int nemo_similarity_table_partial(nemo_mesh_t m, const float* feat, int32_t B, int32_t HW, const int32_t* table_ranges,
+                                             const int32_t* only_flagged, float* table, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!m || !feat || !table || B < 0 || HW <= 0 || (!table_ranges && !only_flagged))
+        return fail(NEMO_ERR_INVALID, "nemo_similarity_table_partial: bad argument");
+    if (!m->bank_frag) return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table_partial: channel count must be 16, 32, 64 or 128");
+    if (nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, table_ranges, only_flagged, (hipStream_t)stream))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table_partial: too many tiles for one launch");
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

@@ -68,6 +68,7 @@ struct LdsLayout {
     int opt;                    // optimiser state (solve kernel) + queue counter
     int sched;                  // float2 [kSchedSteps]: per-step Adam step size and sqrt of the second bias correction
     int flist;                  // u16 [F]: faces that look at the camera this step (optimisation loop; -1: not kept)
+    int need;                   // u32 [kNeedBlocks]: per 32-vertex block the pixel tiles its table rows exist for (optimisation loop; -1: none)
     int total;
 };
 
@@ -94,6 +95,7 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
     L.opt = o; o = align16(o + 256);
     L.sched = o; o = align16(o + 8 * kSchedSteps);
     L.flist = -1;
+    L.need = -1;
     L.total = o;
     return L;
 }
@@ -101,6 +103,7 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
 // Layout of the optimisation loop: 32-bit keys (quantised depth above the face index), the covered entries
 // are compacted in place into the key buffer (no queue) and a face is three 16-bit vertex indices.  Half the
 // size of the layout above, so that two workgroups share a compute unit.
+constexpr int kNeedBlocks = 256;          // partial similarity tables: at most this many 32-vertex blocks (block ids travel as bytes)
 constexpr int kPackedFaceVerts = 1 << 16;     // faces are kept in LDS only when the vertex indices fit 16 bits
 inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds, int waves) {
     LdsLayout L;
@@ -119,6 +122,7 @@ inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds
     L.opt = o; o = align16(o + 256);
     L.sched = o; o = align16(o + 8 * kSchedSteps);
     if (F < (1 << 16)) { L.flist = o; o = align16(o + 2 * F); } else L.flist = -1;
+    L.need = o; o = align16(o + 4 * kNeedBlocks);
     L.total = o;
     return L;
 }
@@ -150,6 +154,8 @@ struct Lds {
     unsigned int* queue;
     unsigned int* qcount;    // [4]: render kernels: pairs in the near / far half; optimisation loop: row range, task counter, front faces
     unsigned short* flist;   // optimisation loop: front-face list or nullptr
+    unsigned int* need;      // optimisation loop with a partial table: first | last << 16 pixel tile per 32-vertex block, or nullptr
+    int* miss;               // global flag of this hypothesis: set when a face needs a table tile outside those ranges
     PoseCam* pc;
     char* opt;
 };
@@ -168,6 +174,8 @@ __device__ inline Lds carve(char* base, const LdsLayout& L) {
     s.opt = base + L.opt;
     s.qcount = (unsigned int*)(base + L.opt + 240);
     s.flist = L.flist >= 0 ? (unsigned short*)(base + L.flist) : nullptr;
+    s.need = L.need >= 0 ? (unsigned int*)(base + L.need) : nullptr;
+    s.miss = nullptr;
     return s;
 }
 
@@ -698,6 +706,8 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     // the vertex records of the next task are requested before the pixel walk of the current one
     FaceVerts nfv;
     int nf = 0;
+    unsigned int nblk = 0;                      // 32-vertex blocks of the face's vertices, a byte each (partial tables)
+    bool miss = false;
     {
         const int idx = task * 64 + lane;
         int i0 = 0, i1 = 0, i2 = 0;
@@ -706,11 +716,13 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
             load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
         }
         nfv = face_verts(s, i0, i1, i2);
+        nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
     }
     while (task < ntask) {
         const bool valid = task * 64 + lane < nfaces;
         const int f = nf;
         const FaceVerts fv = nfv;
+        const unsigned int blk = nblk;
         unsigned int nt = 0;
         if (lane == 0) nt = atomicAdd(&s.qcount[2], 1u);
         const int next = (int)__builtin_amdgcn_readfirstlane(nt);
@@ -722,11 +734,25 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
                 load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
             }
             nfv = face_verts(s, i0, i1, i2);
+            nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
         }
         WalkState w;
         int box[4];
         const bool slow = walk_setup(g, f, valid, cull, rc.depth_scale, fv, &w, box);
-        if (w.n > 0 || slow) { row_lo = min(row_lo, g.H - 1 - box[3]); row_hi = max(row_hi, g.H - 1 - box[1]); }
+        if (w.n > 0 || slow) {
+            const int r0 = g.H - 1 - box[3], r1 = g.H - 1 - box[1];
+            row_lo = min(row_lo, r0); row_hi = max(row_hi, r1);
+            if (s.need) {
+                // partial table: the pixels this face can cover lie in rows [r0, r1]; the table rows of its three
+                // vertices must exist for the 128-pixel tiles of those rows
+                const int t0 = (r0 * g.W) >> 7, t1 = (r1 * g.W + g.W - 1) >> 7;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const unsigned int r = s.need[(blk >> (8 * j)) & 255u];
+                    miss |= t0 < (int)(r & 0xFFFFu) || t1 > (int)(r >> 16);
+                }
+            }
+        }
         if (__any(slow)) {                       // rare: a face crossing the camera plane
             if (slow)
                 for (int jy = box[1]; jy <= box[3]; ++jy)
@@ -761,6 +787,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
 #endif
     // rows that can hold covered pixels: s.qcount[0] = first, s.qcount[1] = last + 1 (the caller keeps
     // them at H and 0 between steps)
+    if (miss && s.miss) *s.miss = 1;
     row_lo = wave_min(row_lo); row_hi = wave_max(row_hi);
     if (lane == 0 && row_hi >= row_lo) {
         atomicMin(&s.qcount[0], (unsigned)row_lo);

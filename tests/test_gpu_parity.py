@@ -448,6 +448,54 @@ def test_full_size_batch_properties(full):
     assert errs[B // 2] < 0.5 and errs[int(B * 0.9)] < 2.0, errs
 
 
+@pytest.mark.parametrize("which,B,margin", [("full", 64, 28), ("full", 16, 0), ("small", 12, 1)])
+def test_partial_table_equals_complete_table(which, B, margin, request):
+    """The partial similarity table (only the pixel tiles a 32-vertex block is expected to meet, from the starting
+    pose) with the repeat of the hypotheses that left their ranges: every result row equals, bit for bit, the one
+    from the complete table.  With a generous margin nothing is flagged and most of the table is skipped; with no
+    margin and starts far from the answer hypotheses are flagged, repeated, and still equal."""
+    from nemo_amd import ops
+    sc = request.getfixturevalue(which)
+    dev = sc.device
+    g = torch.Generator().manual_seed(15)
+    u = torch.rand(B, 3, generator=g)
+    gaz, gel, gth = u[:, 0] * 2 * math.pi, -math.pi / 6 + u[:, 1] * math.pi / 2, -math.pi / 6 + u[:, 2] * math.pi / 3
+    campos = R.camera_position_from_spherical_angles(torch.full((B,), 5.0), gel, gaz).to(dev)
+    with torch.no_grad():
+        fm = sc.mod(campos, gth.float().to(dev))
+    clutter = sc.clutter.to(dev)
+    bg = (fm.abs().sum(dim=1, keepdim=True) == 0).float()
+    noise = torch.randn(fm.shape, generator=torch.Generator().manual_seed(16)).to(dev)
+    fm = torch.nn.functional.normalize(fm + bg * clutter.view(1, -1, 1, 1) + 0.5 / math.sqrt(sc.C) * noise, dim=1).contiguous()
+    clu = ops.clutter_score(fm, clutter)
+    spread = 0.2 if margin > 1 else 0.6                      # how far from the answer the optimisation starts
+    d = (torch.rand(B, 3, generator=g) - 0.5) * 2 * spread
+    C0 = R.camera_position_from_spherical_angles(torch.full((B,), 5.0), gel + d[:, 1], gaz + d[:, 0]).to(dev)
+    th0 = (gth + d[:, 2]).float().to(dev)
+    cam = sc.mod.camera()
+    kw = dict(global_batch=B, steps=300, lr_every=100)
+    tab = ops.similarity_table(sc.mod.mesh, fm)
+    dense, _ = ops.solve(sc.mod.mesh, cam, tab, clu, C0, th0, **kw)
+    table = torch.full(ops.table_shape(sc.mod.mesh, B, sc.H * sc.W), float("nan"), device=dev)   # stale contents must never matter
+    pose, flags = ops.solve_on_partial_table(sc.mod.mesh, cam, fm, clu, C0, th0, margin_rows=margin, table=table, **kw)
+    assert torch.equal(pose, dense)
+    ranges = ops.table_ranges(sc.mod.mesh, cam, C0, th0, margin_rows=margin)
+    npt = table.shape[1]
+    lo, hi = ranges[..., 0].clamp(min=0), ranges[..., 1].clamp(max=npt - 1)
+    frac = float((hi - lo + 1).clamp(min=0).sum()) / (B * ranges.shape[1] * npt)
+    n_flag = int(flags.sum())
+    if margin > 1:
+        assert n_flag == 0 and frac < 0.9, (n_flag, frac)
+        # the computed part is the complete table's, the rest was not touched
+        filled = ~torch.isnan(table)
+        assert torch.equal(table[filled], tab[filled]) and 0.2 < float(filled.float().mean()) < 0.92
+    else:
+        assert 0 < n_flag, (n_flag, frac)
+        assert torch.equal(table[flags.bool()], tab[flags.bool()])                                  # flagged images got their whole table
+    with pytest.raises(RuntimeError):
+        ops.solve_partial(sc.mod.mesh, cam, tab, clu, C0, th0)                                       # neither ranges nor flags
+
+
 # ---- committed golden fixtures (tests/golden, made by oracle/gen_golden.py) -----------------------------
 import os
 
