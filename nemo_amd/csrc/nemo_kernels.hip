@@ -894,7 +894,7 @@ struct SolveArgs {
 // (flow_warp.py: grid_sample, align_corners=True, border padding) before it is compared with the image.
 // Two workgroups per compute unit (four waves per SIMD, 128 registers): while one hypothesis is in a serial
 // section (pose set-up, the gradient chain, Adam) or waits on LDS, the other one's waves issue.
-template <bool FL, bool WARP>
+template <bool FL, bool WARP, bool PARTIAL = false>
 __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     const int vg_n = (V + 3) >> 2;
     const float* clu = a.clu + (size_t)img * HW;
     solve_prologue(a.rc, s);
-    if (a.ranges) {
+    if (PARTIAL) {
         for (int k = tid; k < a.nvb; k += blockDim.x) {
             const int32_t* r = a.ranges + ((size_t)img * a.nvb + k) * 2;
             s.need[k] = (unsigned)min(max(r[0], 0), 0xFFFF) | (unsigned)min(max(r[1], 0), 0xFFFF) << 16;
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         STAMP(0);
         if (verts_resident) project_vertices_resident(a.rc, s, wv); else project_vertices(a.rc, s);
         STAMP(1);
-        raster_direct<FL>(a.rc, s);
+        raster_direct<FL, PARTIAL>(a.rc, s);
 #ifdef NEMO_STAMPS_P1
         if (tid == 0 && a.out_hist) for (int k = 0; k < 6; ++k) a.out_hist[(size_t)h * a.steps + 16 + k] += s.tot[k] / (float)a.steps;
 #endif
@@ -1260,7 +1260,8 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* table,
         if (a.nvb > kNeedBlocks || !m->bank_frag)
             return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_partial: at most %d vertices and a channel count of 16, 32, 64 or 128", 32 * kNeedBlocks);
     }
-    auto kern = a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>;
+    auto kern = table_ranges ? (a.rc.L.faces >= 0 ? solve_kernel<true, false, true> : solve_kernel<false, false, true>)
+                             : (a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>);
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

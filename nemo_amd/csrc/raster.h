@@ -656,7 +656,8 @@ __device__ inline void walk_step(WalkState& w, int k, unsigned int* zkey, float 
 // index and takes the next one from an LDS counter (s.qcount[2], which the caller keeps at the number
 // of waves between steps), so waves whose faces have small boxes pick up more tasks.  The caller keeps
 // s.qcount[3] (length of the list) at 0 between steps.
-template <bool FACES_LDS>
+// PARTIAL: the similarity table exists only for the tile ranges in s.need; a face that needs more sets *s.miss.
+template <bool FACES_LDS, bool PARTIAL>
 __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     WalkGrid g;
     g.H = rc.cc.H; g.W = rc.cc.W;
@@ -716,7 +717,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
             load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
         }
         nfv = face_verts(s, i0, i1, i2);
-        nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
+        if (PARTIAL) nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
     }
     while (task < ntask) {
         const bool valid = task * 64 + lane < nfaces;
@@ -734,7 +735,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
                 load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
             }
             nfv = face_verts(s, i0, i1, i2);
-            nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
+            if (PARTIAL) nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
         }
         WalkState w;
         int box[4];
@@ -742,7 +743,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
         if (w.n > 0 || slow) {
             const int r0 = g.H - 1 - box[3], r1 = g.H - 1 - box[1];
             row_lo = min(row_lo, r0); row_hi = max(row_hi, r1);
-            if (s.need) {
+            if (PARTIAL) {
                 // partial table: the pixels this face can cover lie in rows [r0, r1]; the table rows of its three
                 // vertices must exist for the 128-pixel tiles of those rows
                 const int t0 = (r0 * g.W) >> 7, t1 = (r1 * g.W + g.W - 1) >> 7;
@@ -787,7 +788,7 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
 #endif
     // rows that can hold covered pixels: s.qcount[0] = first, s.qcount[1] = last + 1 (the caller keeps
     // them at H and 0 between steps)
-    if (miss && s.miss) *s.miss = 1;
+    if (PARTIAL && miss && s.miss) *s.miss = 1;
     row_lo = wave_min(row_lo); row_hi = wave_max(row_hi);
     if (lane == 0 && row_hi >= row_lo) {
         atomicMin(&s.qcount[0], (unsigned)row_lo);
