@@ -130,6 +130,18 @@ int nemo_grid_score(const float* pre, const float* feat, const float* clu, int32
                     int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* nemo_grid_score for callers that cannot allocate device memory or hand over a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * per-tile partial sums go to a fixed array of NEMO_STATIC_SCRATCH_BYTES that the library holds on every GPU
+ * it runs on until the process ends; the call allocates and frees nothing.  Sizes whose partial sums
+ * (nemo_grid_score_workspace(N, B, HW) bytes) exceed the array are refused with NEMO_ERR_UNSUPPORTED.  All
+ * calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams or host
+ * threads) race on it; calls that follow each other on one stream do not. */
+#define NEMO_STATIC_SCRATCH_BYTES (16u << 20)
+int nemo_grid_score_static(const float* pre, const float* feat, const float* clu, int32_t N, int32_t B,
+                           int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
+                           void* stream);
+
 /* The same scoring on the matrix cores (v_mfma_f32_32x32x16_f16 on two-piece f16 operands: f32-grade
  * accuracy).  The pre-rendered grid is packed once, next to its rendering (batch_solve_pose.py:43-62),
  * into pixel-major fragment order; every call then converts the batch's feature maps to the same

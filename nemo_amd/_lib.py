@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libnemo_hip.so")
 SYMBOLS = [
     "nemo_last_error", "nemo_version", "nemo_mesh_create", "nemo_mesh_set_memory", "nemo_mesh_destroy",
     "nemo_mesh_info", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
-    "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_pack_bytes", "nemo_grid_pack",
+    "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_score_static", "nemo_grid_pack_bytes", "nemo_grid_pack",
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
     "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
@@ -61,6 +61,7 @@ def load():
     lib.nemo_grid_score_workspace.argtypes = [i32, i32, i32]
     lib.nemo_grid_score_workspace.restype = C.c_size_t
     lib.nemo_grid_score.argtypes = [f32p, f32p, f32p, i32, i32, i32, i32, f32p, vp, f32p, vp, C.c_size_t, vp]
+    lib.nemo_grid_score_static.argtypes = [f32p, f32p, f32p, i32, i32, i32, i32, f32p, vp, f32p, vp]
     lib.nemo_grid_pack_bytes.argtypes = [i32, i32, i32]
     lib.nemo_grid_pack_bytes.restype = C.c_size_t
     lib.nemo_grid_pack.argtypes = [f32p, i32, i32, i32, vp, vp]

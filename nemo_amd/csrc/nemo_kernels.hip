@@ -18,6 +18,7 @@
 #include <string.h>
 #include <new>
 #include <map>
+#include <mutex>
 #include <array>
 #include <vector>
 #include <utility>
@@ -725,6 +726,47 @@ extern "C" int nemo_grid_score(const float* pre, const float* feat, const float*
                        out_loss, out_argmin, out_min);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
+}
+
+// ---- the same scoring for callers that cannot allocate ----
+// The per-tile partial sums go to a fixed device array instead of a caller workspace.  In host code the name
+// `scratch` is only a handle for hipGetSymbolAddress: its device address is looked up once per device (each GPU
+// holds its own copy of the array at its own address) and the kernels always take that looked-up pointer.
+static __device__ __align__(256) float scratch[NEMO_STATIC_SCRATCH_BYTES / sizeof(float)];
+constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+static int static_scratch(float** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(NEMO_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(NEMO_ERR_HIP, "hipGetSymbolAddress returned a null address for the static scratch array");
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return NEMO_OK;
+}
+
+extern "C" int nemo_grid_score_static(const float* pre, const float* feat, const float* clu, int32_t N, int32_t B, int32_t C,
+                                      int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!pre || !feat || !out_argmin || N <= 0 || B < 0 || C <= 0 || HW <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_static: bad argument");
+    const size_t need = nemo_grid_score_workspace(N, B, HW);
+    if (need > (size_t)NEMO_STATIC_SCRATCH_BYTES)
+        return fail(NEMO_ERR_UNSUPPORTED,
+                    "nemo_grid_score_static: %d poses x %d images x %d pixels need %zu bytes of partial sums, the static scratch "
+                    "array holds %zu (use nemo_grid_score with a workspace)", N, B, HW, need, (size_t)NEMO_STATIC_SCRATCH_BYTES);
+    float* partial = nullptr;
+    const int rc = static_scratch(&partial);
+    if (rc) return rc;
+    // every partial sum the finalize kernel reads is written by the scoring kernel of this call: nothing to clear
+    return nemo_grid_score(pre, feat, clu, N, B, C, HW, out_loss, out_argmin, out_min, partial, need, stream);
 }
 
 // ---- matrix-core form (kernels in grid_mfma.hip) ----

@@ -249,6 +249,23 @@ def grid_score(pre_rendered, feature_map, clutter_score_map=None, packed=None):
     return loss, amin, mn
 
 
+def grid_score_static(pre_rendered, feature_map, clutter_score_map, out_loss, out_argmin, out_min):
+    """grid_score through the entry point that allocates nothing: the caller brings every tensor (inputs float32
+    contiguous on the device, out_loss [B,N] f32, out_argmin [B] i32, out_min [B] f32) and the library keeps the
+    partial sums in its own fixed device array.  Calls that overlap on one GPU race on that array."""
+    lib = _lib.load()
+    N, Cc, H, W = pre_rendered.shape
+    B = feature_map.shape[0]
+    if tuple(feature_map.shape[1:]) != (Cc, H, W) or tuple(out_loss.shape) != (B, N) or out_argmin.numel() != B or out_min.numel() != B:
+        raise ValueError("shapes of the grid, the feature maps and the outputs do not match")
+    if clutter_score_map is not None and clutter_score_map.numel() != B * H * W:
+        raise ValueError("clutter_score_map must be [B,H,W]")
+    with torch.cuda.device(feature_map.device):
+        check(lib.nemo_grid_score_static(ptr(pre_rendered), ptr(feature_map), ptr(clutter_score_map), N, B, Cc, H * W, ptr(out_loss),
+                                         ptr(out_argmin, torch.int32), ptr(out_min), stream_ptr()), "nemo_grid_score_static")
+    return out_loss, out_argmin, out_min
+
+
 def grid_score_recentred(packed, feature_map, clutter_score_map, dist_src, dist_tgt, p_src, p_tgt, padding_mode="border"):
     """Scores re-centred copies of a batch against a packed grid without materialising them.
     feature_map [B,C,h1,w1], clutter_score_map [B,h1,w1] or None; dist_src / dist_tgt [nv], p_src / p_tgt [nv,2]
