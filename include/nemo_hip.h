@@ -64,10 +64,22 @@ const char* nemo_version(void);
  * (nemo/models/mesh_interpolate_module.py:92-150): the mesh and the per-vertex feature memory.
  * The handle keeps its own device copies (verts [V,3] f32, faces [F,3] i32, memory [V,C] f32
  * and its transpose [C,V]).  face_memory[f,j,:] of the reference == memory[faces[f,j],:]
- * (nemo/utils/mesh.py:173-174) and is never materialised. */
+ * (nemo/utils/mesh.py:173-174) and is never materialised.
+ * nemo_mesh_create copies verts / faces synchronously (null-stream copies to the device and to the host, where the
+ * mesh is checked for being a closed solid): the caller's buffers must be complete on the device before the call,
+ * i.e. work that produces them on a non-blocking stream has to be synchronised first.  On failure nothing stays
+ * allocated. */
 int nemo_mesh_create(const float* verts, const int32_t* faces, int32_t V, int32_t F, nemo_mesh_t* out);
 int nemo_mesh_set_memory(nemo_mesh_t mesh, const float* memory /*[V,C]*/, int32_t C, void* stream);
 int nemo_mesh_destroy(nemo_mesh_t mesh);
+/* A handle may hold several meshes back to back - the layout of a multi-class FeatureBankNeMo, whose memory is the
+ * per-mesh vertex blocks concatenated (nemo/models/feature_banks.py:133-163, offsets as in
+ * cu_layers/CuNeMo/gather_features.py:31; the reference keeps one MeshInterpolateModule per category instead,
+ * nemo/models/nemo_cls.py:156-168).  Create it from the concatenated vertices and the concatenated faces (face
+ * indices into the concatenated vertex list), then name the parts: part l = the next vert_counts[l] vertices and
+ * the next face_counts[l] faces (HOST arrays of n_parts entries; every face must stay inside its part's vertices).
+ * nemo_similarity_table then covers all meshes at once and nemo_solve_parts renders one part per hypothesis. */
+int nemo_mesh_set_parts(nemo_mesh_t mesh, const int32_t* vert_counts, const int32_t* face_counts, int32_t n_parts);
 int nemo_mesh_info(nemo_mesh_t mesh, int32_t* V, int32_t* F, int32_t* C);
 
 /* ---- camera / projection (diagnostic + parity) -------------------------------------------
@@ -215,6 +227,18 @@ int nemo_solve(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, con
                const float* init_theta /*[n_hyp]*/, const float* init_principal /*[n_hyp,2] or NULL*/,
                const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
                const nemo_adam* opt, float* out_pose, float* out_loss_hist, void* stream);
+
+/* nemo_solve on a handle of several meshes (nemo_mesh_set_parts): hypothesis h refines the pose of mesh
+ * hyp_to_part[h] (device, [n_hyp]) against image hyp_to_image[h]; `table` is the similarity table of the whole
+ * handle.  One launch does what the reference does category by category: the per-category pose solves of
+ * scripts/inference.py:29-96 with a multi-class bank, and render-and-compare classification, where every image is
+ * solved against every category mesh and the smallest final loss names the class (nemo/models/nemo_cls.py:262-282).
+ * A hypothesis whose part index names no part gets a NaN row. */
+int nemo_solve_parts(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, const float* clu,
+                     const int32_t* hyp_to_image, const int32_t* hyp_to_part, const float* init_campos,
+                     const float* init_theta, const float* init_principal, const int32_t* score_boxes, int32_t n_hyp,
+                     int32_t n_img, int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose,
+                     float* out_loss_hist, void* stream);
 
 /* ---- keypoint-initialised solver (nemo/models/solve_pose.py) ----------------------------------
  * get_corr_pytorch (solve_pose.py:27-82) on the similarity table of ONE image:

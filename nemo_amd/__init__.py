@@ -9,9 +9,10 @@ from .cameras import MeshRasterizer, PerspectiveCameras, RasterizationSettings
 from . import cu_nemo
 from .feature_banks import FeatureBankNeMo, MaskCreater
 from .mesh_interpolate_module import MeshInterpolateModule
+from .multi_category import MultiCategorySolver
 from .nemo import NeMo, classify_by_render_compare
 from . import solve_pose_keypoint
 from .project_kp import PackedRaster
 
 __all__ = ["ops", "get_pre_render_samples", "solve_pose", "MeshRasterizer", "PerspectiveCameras",
-           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "MaskCreater", "cu_nemo", "NeMo", "classify_by_render_compare", "solve_pose_keypoint", "PackedRaster"]
+           "RasterizationSettings", "MeshInterpolateModule", "FeatureBankNeMo", "MaskCreater", "cu_nemo", "NeMo", "classify_by_render_compare", "MultiCategorySolver", "solve_pose_keypoint", "PackedRaster"]

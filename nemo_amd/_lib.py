@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libnemo_hip.so")
 # every symbol include/nemo_hip.h declares
 SYMBOLS = [
     "nemo_last_error", "nemo_version", "nemo_mesh_create", "nemo_mesh_set_memory", "nemo_mesh_destroy",
-    "nemo_mesh_info", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
+    "nemo_mesh_info", "nemo_mesh_set_parts", "nemo_solve_parts", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
     "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_score_static", "nemo_grid_pack_bytes", "nemo_grid_pack",
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
@@ -78,6 +78,9 @@ def load():
     lib.nemo_vertex_similarity.argtypes = [vp, f32p, f32p, vp, i32, i32, i32, f32p, vp]
     lib.nemo_solve.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, f32p, f32p, f32p, vp, i32, i32, i32, i32,
                                C.POINTER(NemoAdam), f32p, f32p, vp]
+    lib.nemo_mesh_set_parts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), i32]
+    lib.nemo_solve_parts.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, vp, f32p, f32p, f32p, vp, i32, i32, i32, i32,
+                                     C.POINTER(NemoAdam), f32p, f32p, vp]
     lib.nemo_keypoint_corr.argtypes = [vp, f32p, f32p, f32p, vp, vp, i32, i32, i32, C.c_float, i32, i32, f32p, vp]
     lib.nemo_solve_flow.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, f32p, f32p, f32p, i32, i32, i32, i32, C.c_float,
                                     C.POINTER(NemoAdam), f32p, f32p, vp]

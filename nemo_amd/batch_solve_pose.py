@@ -110,6 +110,111 @@ def get_init_pos(inter_module, samples_pos, samples_theta, predicted_maps, clutt
         return samples_pos[idx], samples_theta[idx], torch.cat(mn)
 
 
+def _clutter_rows(clutter_bank, c):
+    banks = clutter_bank if isinstance(clutter_bank, list) else [clutter_bank]
+    return torch.cat([cb.reshape(-1, c) for cb in banks], dim=0)
+
+
+def initial_poses(feature_map, clutter_score, cameras, cam_pos_pre_rendered, theta_pre_rendered, feature_pre_rendered,
+                  principal=None, pre_render=True, dof=3, n_hyp=1, inter_module=None, distance_source=None, distance_target=None):
+    """Step 2 of solve_pose (reference batch_solve_pose.py:233-301): pose-grid scoring and the choice of the starting
+    pose(s) of every image.  -> (init_C [b * n_hyp, 3], init_theta [b * n_hyp], init_principal [b * n_hyp, 2] or None),
+    hypothesis-major (rows i * n_hyp + k), best first."""
+    b = feature_map.shape[0]
+    dev = feature_map.device
+    size = cameras.image_size                    # [1, 2] = (H, W)
+    target_shape = (int(size[0, 0]), int(size[0, 1]))
+    centre = size.flip(1) / 2                    # principal point of a centred image (x, y)
+    if dof in (3, 4):
+        if principal is not None:
+            principal = principal.float().to(dev)
+            t_feature_map = align_no_centered(feature_map, distance_source, principal, target_shape, distance_target, centre)
+            t_clutter_score = align_no_centered(clutter_score[:, None], distance_source, principal, target_shape,
+                                                distance_target, centre).squeeze(1)
+            init_principal = principal
+            cameras._N = b
+        else:
+            init_principal = None
+            t_feature_map, t_clutter_score = feature_map, clutter_score
+        if pre_render:
+            init_C, init_theta, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
+                                                               theta_pre_rendered, t_feature_map, t_clutter_score,
+                                                               top_k=n_hyp)
+            if n_hyp > 1:                        # [b, K, ...] -> hypothesis-major rows i * K + k
+                init_C, init_theta = init_C.reshape(b * n_hyp, 3), init_theta.reshape(b * n_hyp)
+                if init_principal is not None:
+                    init_principal = init_principal.reshape(-1, 2).expand(b, 2).repeat_interleave(n_hyp, dim=0)
+        else:
+            ds = distance_source
+            init_C, init_theta, _ = get_init_pos(inter_module, cam_pos_pre_rendered, theta_pre_rendered, feature_map,
+                                                 clutter_score, reset_distance=None if ds is None else ds.float())
+        return init_C, init_theta, init_principal
+    assert pre_render
+    principal = principal.float().to(dev)
+    ones = torch.ones(b, device=dev)
+    # Every principal sample re-centres the whole batch (batch_solve_pose.py:264-295).  The re-centred
+    # copies are scored together, a few samples per grid-scoring launch, so the pre-rendered grid is
+    # streamed once per launch instead of once per sample; results per sample are unchanged.
+    all_C, all_theta, all_loss = [], [], []
+    per_call = max(1, 1024 // max(b, 1))
+    packed = getattr(feature_pre_rendered, "_nemo_packed_grid", None)
+    for s0 in range(0, principal.shape[0], per_call):
+        chunk = principal[s0:s0 + per_call]
+        if packed is not None:
+            # the re-centred copies are never written: the scoring samples the batch's own maps (copy k * b + i
+            # = image i re-centred on principal sample k)
+            nv = chunk.shape[0] * b
+            ones_v = torch.ones(nv, device=dev)
+            _, idx_, loss_ = ops.grid_score_recentred(packed, feature_map, clutter_score, ones_v, ones_v,
+                                                      chunk.repeat_interleave(b, dim=0), centre.to(dev).expand(nv, 2),
+                                                      padding_mode="border")
+            C_, th_ = cam_pos_pre_rendered[idx_.long()], theta_pre_rendered[idx_.long()]
+        else:
+            fms = [align_no_centered(feature_map, ones, p_, target_shape, ones, centre, padding_mode="border") for p_ in chunk]
+            cls = [align_no_centered(clutter_score[:, None], ones, p_, target_shape, ones, centre, padding_mode="border").squeeze(1)
+                   for p_ in chunk]
+            C_, th_, loss_ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered,
+                                                        torch.cat(fms), torch.cat(cls))
+        for k in range(chunk.shape[0]):
+            all_C.append(C_[k * b:(k + 1) * b])
+            all_theta.append(th_[k * b:(k + 1) * b])
+            all_loss.append(loss_[k * b:(k + 1) * b])
+    ar = torch.arange(b, device=dev)
+    if n_hyp > 1:
+        if n_hyp > principal.shape[0]:
+            raise ValueError(f"hypotheses={n_hyp} exceeds the {principal.shape[0]} principal samples")
+        use = torch.sort(torch.stack(all_loss), dim=0, stable=True)[1][:n_hyp].T          # [b, K], best first
+        init_C = torch.stack(all_C)[use, ar[:, None]].reshape(b * n_hyp, 3)
+        init_theta = torch.stack(all_theta)[use, ar[:, None]].reshape(b * n_hyp)
+        init_principal = principal[use].reshape(b * n_hyp, 2)
+    else:
+        use = torch.min(torch.stack(all_loss), dim=0)[1]
+        init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_theta)[use, ar]
+        init_principal = principal[use]
+    cameras._N = b
+    return init_C, init_theta, init_principal
+
+
+def score_boxes_from_bbox(bbox, b, n_hyp, rate):
+    """The crop of the reported score (batch_solve_pose.py:354-357): rows / cols int(bbox / rate + .5), one row per hypothesis."""
+    boxes = torch.tensor([[int(float(v) / rate + .5) for v in bbox[i][:4]] for i in range(b)], dtype=torch.int32)
+    return boxes.repeat_interleave(n_hyp, dim=0)
+
+
+def pack_predictions(host, b, n_hyp, times):
+    """host [b * n_hyp, 11] = the 8 solve columns + (distance, elevation, azimuth) -> the reference's list of dicts
+    (batch_solve_pose.py:340-372), the n_hyp refined poses of an image best score first."""
+    preds = []
+    for i in range(b):
+        rows = host[i * n_hyp:(i + 1) * n_hyp]
+        refined = [{
+            "azimuth": float(r[10]), "elevation": float(r[9]), "theta": float(r[3]), "distance": float(r[8]),
+            "principal": [float(r[4]), float(r[5])], "score": float(r[6]),
+        } for r in rows[np.argsort(rows[:, 6], kind="stable")]]
+        preds.append(dict(final=refined, **{k: times[k] / b for k in times.keys()}))
+    return preds
+
+
 def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendered, theta_pre_rendered,
                feature_pre_rendered, device="cuda", principal=None, pre_render=True, dof=3, bbox=None, **kwargs):
     """Same contract as the reference (batch_solve_pose.py:194-372): a list (one entry per image) of
@@ -138,85 +243,19 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
 
     # Step 1: clutter score
     t0 = time.time()
-    banks = clutter_bank if isinstance(clutter_bank, list) else [clutter_bank]
-    clutter = torch.cat([cb.reshape(-1, c) for cb in banks], dim=0)
-    clutter_score = ops.clutter_score(feature_map, clutter)
+    clutter_score = ops.clutter_score(feature_map, _clutter_rows(clutter_bank, c))
     t1 = time.time()
     pred["pre_compute_time"] = t1 - t0
 
     # Step 2: initialisation by pose-grid scoring
-    cams = inter_module.rasterizer.cameras
-    size = cams.image_size                       # [1, 2] = (H, W)
-    target_shape = (int(size[0, 0]), int(size[0, 1]))
-    centre = size.flip(1) / 2                    # principal point of a centred image (x, y)
-    if dof in (3, 4):
-        if principal is not None:
-            principal = principal.float().to(dev)
-            t_feature_map = align_no_centered(feature_map, kwargs["distance_source"], principal, target_shape,
-                                              kwargs["distance_target"], centre)
-            t_clutter_score = align_no_centered(clutter_score[:, None], kwargs["distance_source"], principal, target_shape,
-                                                kwargs["distance_target"], centre).squeeze(1)
-            init_principal = principal
-            cams._N = b
-        else:
-            init_principal = None
-            t_feature_map, t_clutter_score = feature_map, clutter_score
-        if pre_render:
-            init_C, init_theta, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
-                                                               theta_pre_rendered, t_feature_map, t_clutter_score,
-                                                               top_k=n_hyp)
-            if n_hyp > 1:                        # [b, K, ...] -> hypothesis-major rows i * K + k
-                init_C, init_theta = init_C.reshape(b * n_hyp, 3), init_theta.reshape(b * n_hyp)
-                if init_principal is not None:
-                    init_principal = init_principal.reshape(-1, 2).expand(b, 2).repeat_interleave(n_hyp, dim=0)
-        else:
-            ds = kwargs.get("distance_source")
-            init_C, init_theta, _ = get_init_pos(inter_module, cam_pos_pre_rendered, theta_pre_rendered, feature_map,
-                                                 clutter_score, reset_distance=None if ds is None else ds.float())
+    if dof in (3, 4) and principal is not None:
+        ds_kw, dt_kw = kwargs["distance_source"], kwargs["distance_target"]
     else:
-        assert pre_render
-        principal = principal.float().to(dev)
-        ones = torch.ones(b, device=dev)
-        # Every principal sample re-centres the whole batch (batch_solve_pose.py:264-295).  The re-centred
-        # copies are scored together, a few samples per grid-scoring launch, so the pre-rendered grid is
-        # streamed once per launch instead of once per sample; results per sample are unchanged.
-        all_C, all_theta, all_loss = [], [], []
-        per_call = max(1, 1024 // max(b, 1))
-        packed = getattr(feature_pre_rendered, "_nemo_packed_grid", None)
-        for s0 in range(0, principal.shape[0], per_call):
-            chunk = principal[s0:s0 + per_call]
-            if packed is not None:
-                # the re-centred copies are never written: the scoring samples the batch's own maps (copy k * b + i
-                # = image i re-centred on principal sample k)
-                nv = chunk.shape[0] * b
-                ones_v = torch.ones(nv, device=dev)
-                _, idx_, loss_ = ops.grid_score_recentred(packed, feature_map, clutter_score, ones_v, ones_v,
-                                                          chunk.repeat_interleave(b, dim=0), centre.to(dev).expand(nv, 2),
-                                                          padding_mode="border")
-                C_, th_ = cam_pos_pre_rendered[idx_.long()], theta_pre_rendered[idx_.long()]
-            else:
-                fms = [align_no_centered(feature_map, ones, p_, target_shape, ones, centre, padding_mode="border") for p_ in chunk]
-                cls = [align_no_centered(clutter_score[:, None], ones, p_, target_shape, ones, centre, padding_mode="border").squeeze(1)
-                       for p_ in chunk]
-                C_, th_, loss_ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered, theta_pre_rendered,
-                                                            torch.cat(fms), torch.cat(cls))
-            for k in range(chunk.shape[0]):
-                all_C.append(C_[k * b:(k + 1) * b])
-                all_theta.append(th_[k * b:(k + 1) * b])
-                all_loss.append(loss_[k * b:(k + 1) * b])
-        ar = torch.arange(b, device=dev)
-        if n_hyp > 1:
-            if n_hyp > principal.shape[0]:
-                raise ValueError(f"hypotheses={n_hyp} exceeds the {principal.shape[0]} principal samples")
-            use = torch.sort(torch.stack(all_loss), dim=0, stable=True)[1][:n_hyp].T          # [b, K], best first
-            init_C = torch.stack(all_C)[use, ar[:, None]].reshape(b * n_hyp, 3)
-            init_theta = torch.stack(all_theta)[use, ar[:, None]].reshape(b * n_hyp)
-            init_principal = principal[use].reshape(b * n_hyp, 2)
-        else:
-            use = torch.min(torch.stack(all_loss), dim=0)[1]
-            init_C, init_theta = torch.stack(all_C)[use, ar], torch.stack(all_theta)[use, ar]
-            init_principal = principal[use]
-        cams._N = b
+        ds_kw, dt_kw = kwargs.get("distance_source"), kwargs.get("distance_target")
+    init_C, init_theta, init_principal = initial_poses(
+        feature_map, clutter_score, inter_module.rasterizer.cameras, cam_pos_pre_rendered, theta_pre_rendered,
+        feature_pre_rendered, principal=principal, pre_render=pre_render, dof=dof, n_hyp=n_hyp, inter_module=inter_module,
+        distance_source=ds_kw, distance_target=dt_kw)
     t2 = time.time()
     pred["pre_rendering_time"] = t2 - t1
 
@@ -227,11 +266,7 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
         init_C = init_C / init_C.pow(2).sum(-1).pow(.5)[..., None] * ds[..., None]
     opt_dof = 6 if (dof == 6 or cfg.get("optimize_translation", False)) else dof
     cam = inter_module.camera()
-    boxes = None
-    if bbox is not None:
-        rate = kwargs.get("down_sample_rate", 8)
-        boxes = torch.tensor([[int(float(v) / rate + .5) for v in bbox[i][:4]] for i in range(b)], dtype=torch.int32)
-        boxes = boxes.repeat_interleave(n_hyp, dim=0)
+    boxes = None if bbox is None else score_boxes_from_bbox(bbox, b, n_hyp, kwargs.get("down_sample_rate", 8))
     table = ops.similarity_table(inter_module.mesh, feature_map)
     pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, init_principal, h2i,
                         global_batch=kwargs.get("global_batch", b), dof=opt_dof, steps=epochs,
@@ -240,13 +275,4 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     host = torch.cat([pose, sph], dim=1).cpu().numpy()     # the one device->host copy
     t3 = time.time()
     pred["optimization_time"] = t3 - t2
-
-    preds = []
-    for i in range(b):
-        rows = host[i * n_hyp:(i + 1) * n_hyp]
-        refined = [{
-            "azimuth": float(r[10]), "elevation": float(r[9]), "theta": float(r[3]), "distance": float(r[8]),
-            "principal": [float(r[4]), float(r[5])], "score": float(r[6]),
-        } for r in rows[np.argsort(rows[:, 6], kind="stable")]]
-        preds.append(dict(final=refined, **{k: pred[k] / b for k in pred.keys()}))
-    return preds
+    return pack_predictions(host, b, n_hyp, pred)

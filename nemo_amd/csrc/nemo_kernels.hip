@@ -68,6 +68,11 @@ struct nemo_mesh_s {
     int32_t* faces_outward;   // [F,3]: the faces wound counter-clockwise seen from outside, or null (see orient_faces)
     float aabb[6];            // xmin, ymin, zmin, xmax, ymax, zmax of the vertices
     int device;
+    // several meshes back to back in one handle (a multi-class bank): part l = vertices [v0, v0 + nv), faces [f0, f0 + nf)
+    std::vector<float> host_verts;      // copies kept for nemo_mesh_set_parts
+    std::vector<int32_t> host_faces;
+    std::vector<nemo::MeshPart> parts;
+    nemo::MeshPart* d_parts;            // device copy of `parts`, or null
 };
 
 // Watertight-and-orientable test of a triangle mesh and outward re-winding of its faces (host, once per
@@ -195,33 +200,99 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
+// Depth-key quantisation range of a set of vertices with bounding box `aabb` (see depth_key32): the bounding
+// radius about the mesh origin is the farthest corner of the box.
+static void depth_range(const float* aabb, int face_bits, float* margin, float* scale, float* qmax) {
+    float r2 = 0.0f;
+    for (int c = 0; c < 8; ++c) {
+        float d2 = 0.0f;
+        for (int k = 0; k < 3; ++k) { const float x = aabb[(c >> k & 1) ? 3 + k : k]; d2 += x * x; }
+        r2 = d2 > r2 ? d2 : r2;
+    }
+    *margin = 1.02f * sqrtf(r2) + 1e-6f;
+    *qmax = (float)((1u << (32 - face_bits)) - 2u);
+    *scale = *qmax / (2.0f * *margin);
+}
+
+static void box_of(const std::vector<float>& v, int v0, int nv, float* aabb) {
+    for (int k = 0; k < 3; ++k) { aabb[k] = __builtin_inff(); aabb[3 + k] = -__builtin_inff(); }
+    for (int i = v0; i < v0 + nv; ++i)
+        for (int k = 0; k < 3; ++k) {
+            aabb[k] = v[3 * i + k] < aabb[k] ? v[3 * i + k] : aabb[k];
+            aabb[3 + k] = v[3 * i + k] > aabb[3 + k] ? v[3 * i + k] : aabb[3 + k];
+        }
+}
+
+static int mesh_create_impl(nemo_mesh_s* m, const float* verts, const int32_t* faces, int32_t V, int32_t F) {
+    HIP_TRY(hipGetDevice(&m->device));
+    HIP_TRY(hipMalloc((void**)&m->verts, sizeof(float) * 3 * V));
+    HIP_TRY(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * F));
+    // synchronous copies on the null stream: the caller's buffers must be complete on the device before the call
+    HIP_TRY(hipMemcpy(m->verts, verts, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(m->faces, faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToDevice));
+    m->host_verts.resize((size_t)3 * V);
+    m->host_faces.resize((size_t)3 * F);
+    HIP_TRY(hipMemcpy(m->host_verts.data(), verts, sizeof(float) * 3 * V, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(m->host_faces.data(), faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToHost));
+    box_of(m->host_verts, 0, V, m->aabb);
+    std::vector<int32_t> oriented;
+    if (orient_faces(m->host_verts, m->host_faces, V, F, &oriented)) {
+        HIP_TRY(hipMalloc((void**)&m->faces_outward, sizeof(int32_t) * 3 * F));
+        HIP_TRY(hipMemcpy(m->faces_outward, oriented.data(), sizeof(int32_t) * 3 * F, hipMemcpyHostToDevice));
+    }
+    return NEMO_OK;
+}
+
 extern "C" int nemo_mesh_create(const float* verts, const int32_t* faces, int32_t V, int32_t F, nemo_mesh_t* out) {
     if (!verts || !faces || !out || V <= 0 || F <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_create: bad argument");
     nemo_mesh_s* m = new (std::nothrow) nemo_mesh_s();
     if (!m) return fail(NEMO_ERR_INVALID, "out of host memory");
     m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr; m->bank_frag = nullptr; m->faces_outward = nullptr;
-    HIP_TRY(hipGetDevice(&m->device));
-    HIP_TRY(hipMalloc((void**)&m->verts, sizeof(float) * 3 * V));
-    HIP_TRY(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * F));
-    HIP_TRY(hipMemcpy(m->verts, verts, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(m->faces, faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToDevice));
-    {
-        std::vector<float> hv((size_t)3 * V);
-        std::vector<int32_t> hf((size_t)3 * F), oriented;
-        HIP_TRY(hipMemcpy(hv.data(), verts, sizeof(float) * 3 * V, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hf.data(), faces, sizeof(int32_t) * 3 * F, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 3; ++k) { m->aabb[k] = __builtin_inff(); m->aabb[3 + k] = -__builtin_inff(); }
-        for (int i = 0; i < V; ++i)
-            for (int k = 0; k < 3; ++k) {
-                m->aabb[k] = hv[3 * i + k] < m->aabb[k] ? hv[3 * i + k] : m->aabb[k];
-                m->aabb[3 + k] = hv[3 * i + k] > m->aabb[3 + k] ? hv[3 * i + k] : m->aabb[3 + k];
-            }
-        if (orient_faces(hv, hf, V, F, &oriented)) {
-            HIP_TRY(hipMalloc((void**)&m->faces_outward, sizeof(int32_t) * 3 * F));
-            HIP_TRY(hipMemcpy(m->faces_outward, oriented.data(), sizeof(int32_t) * 3 * F, hipMemcpyHostToDevice));
-        }
-    }
+    m->verts = nullptr; m->faces = nullptr; m->d_parts = nullptr;
+    int rc = NEMO_ERR_INVALID;
+    try { rc = mesh_create_impl(m, verts, faces, V, F); } catch (const std::bad_alloc&) { rc = fail(NEMO_ERR_INVALID, "out of host memory"); }
+    if (rc) { (void)nemo_mesh_destroy(m); return rc; }       // frees whatever was allocated before the failure
     *out = m;
+    return NEMO_OK;
+}
+
+// Several meshes in one handle: part l = the next vert_counts[l] vertices and the next face_counts[l] faces (host
+// arrays).  Every face of a part must index vertices of that part.
+extern "C" int nemo_mesh_set_parts(nemo_mesh_t m, const int32_t* vert_counts, const int32_t* face_counts, int32_t n_parts) {
+    if (!m || !vert_counts || !face_counts || n_parts <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: bad argument");
+    std::vector<nemo::MeshPart> parts((size_t)n_parts);
+    int v0 = 0, f0 = 0, fmax = 1;
+    for (int l = 0; l < n_parts; ++l) {
+        if (vert_counts[l] <= 0 || face_counts[l] <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: part %d is empty", l);
+        parts[l].v0 = v0; parts[l].nv = vert_counts[l]; parts[l].f0 = f0; parts[l].nf = face_counts[l];
+        v0 += vert_counts[l]; f0 += face_counts[l];
+        if (v0 > m->V || f0 > m->F) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: the parts exceed the mesh");
+        fmax = face_counts[l] > fmax ? face_counts[l] : fmax;
+    }
+    if (v0 != m->V || f0 != m->F)
+        return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: the parts hold %d vertices / %d faces, the mesh %d / %d", v0, f0, m->V, m->F);
+    int fb = 9;
+    while ((1 << fb) <= fmax) ++fb;
+    for (int l = 0; l < n_parts; ++l) {
+        nemo::MeshPart& q = parts[l];
+        for (int t = 3 * q.f0; t < 3 * (q.f0 + q.nf); ++t)
+            if (m->host_faces[t] < q.v0 || m->host_faces[t] >= q.v0 + q.nv)
+                return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: face %d of part %d uses vertex %d of another part", t / 3 - q.f0, l,
+                            m->host_faces[t]);
+        box_of(m->host_verts, q.v0, q.nv, q.aabb);
+        q.face_bits = fb;
+        depth_range(q.aabb, fb, &q.depth_margin, &q.depth_scale, &q.depth_qmax);
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    nemo::MeshPart* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(nemo::MeshPart) * n_parts));
+    if (hipMemcpy(d, parts.data(), sizeof(nemo::MeshPart) * n_parts, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(NEMO_ERR_HIP, "nemo_mesh_set_parts: copying the part table failed");
+    }
+    if (m->d_parts) (void)hipFree(m->d_parts);
+    m->d_parts = d;
+    m->parts = parts;
     return NEMO_OK;
 }
 
@@ -253,6 +324,7 @@ extern "C" int nemo_mesh_destroy(nemo_mesh_t m) {
     if (m->memory_t) (void)hipFree(m->memory_t);
     if (m->bank_frag) (void)hipFree(m->bank_frag);
     if (m->faces_outward) (void)hipFree(m->faces_outward);
+    if (m->d_parts) (void)hipFree(m->d_parts);
     delete m;
     return NEMO_OK;
 }
@@ -296,16 +368,7 @@ static int plan_solve(int H, int W, int V, int F, int threads, const float* aabb
     int fb = 9;                                    // at most 23 bits of depth: they are read from a float's mantissa
     while ((1 << fb) <= F) ++fb;                   // 2^fb > F: no key equals the empty marker
     rc->face_bits = fb;
-    float r2 = 0.0f;                               // bounding radius about the mesh origin: the farthest corner of the box
-    for (int c = 0; c < 8; ++c) {
-        float d2 = 0.0f;
-        for (int k = 0; k < 3; ++k) { const float x = aabb[(c >> k & 1) ? 3 + k : k]; d2 += x * x; }
-        r2 = d2 > r2 ? d2 : r2;
-    }
-    const float r = sqrtf(r2);
-    rc->depth_margin = 1.02f * r + 1e-6f;
-    rc->depth_qmax = (float)((1u << (32 - fb)) - 2u);
-    rc->depth_scale = rc->depth_qmax / (2.0f * rc->depth_margin);
+    depth_range(aabb, fb, &rc->depth_margin, &rc->depth_scale, &rc->depth_qmax);
     return NEMO_OK;
 }
 
@@ -923,6 +986,8 @@ struct SolveArgs {
     const int32_t* ranges; int nvb;      // partial similarity table: [n_img][nvb][2] first / last pixel tile per 32-vertex block, or null
     int32_t* miss;                       // [n_hyp]: set to 1 when the hypothesis needed a tile outside the ranges (its result is then void)
     const int32_t* only;                 // [n_hyp] or null: hypotheses with a zero entry are left alone
+    const MeshPart* parts; const int32_t* hyp_to_part; int n_parts;   // a handle of several meshes: hypothesis h rasterises part hyp_to_part[h]
+    int table_vg;                        // vertex groups of 4 per pixel tile of the table (all vertices of the handle)
     float def_px, def_py;
     float tscale, inv_tscale;    // warp mode: the reference's translation_scale (flow units per pixel) and its inverse
     int n_img; float inv_norm; int dof;
@@ -941,19 +1006,34 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
     const int h = blockIdx.x, tid = threadIdx.x;
-    const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W, V = a.rc.V;
+    const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W;
     const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
     if (a.only && a.only[h] == 0) return;
-    if ((unsigned)img >= (unsigned)a.n_img) {      // a hypothesis that names no image: NaN row, nothing read
+    // The mesh this hypothesis renders: the whole handle, or one of its parts (uniform over the workgroup).
+    RasterCtx rc = a.rc;
+    int part = 0;
+    if (a.hyp_to_part) {
+        part = a.hyp_to_part[h];
+        if ((unsigned)part < (unsigned)a.n_parts) {
+            const MeshPart q = a.parts[part];
+            rc.verts = a.rc.verts + 3 * (size_t)q.v0; rc.faces = a.rc.faces + 3 * (size_t)q.f0; rc.vbase = q.v0;
+            rc.V = q.nv; rc.F = q.nf;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rc.aabb[k] = q.aabb[k];
+            rc.face_bits = q.face_bits; rc.depth_margin = q.depth_margin; rc.depth_scale = q.depth_scale; rc.depth_qmax = q.depth_qmax;
+        }
+    }
+    const int V = rc.V, vbase = rc.vbase;
+    if ((unsigned)img >= (unsigned)a.n_img || (unsigned)part >= (unsigned)a.n_parts) {      // a hypothesis that names no image / no mesh: NaN row, nothing read
         if (tid < 8) a.out_pose[(size_t)h * 8 + tid] = __builtin_nanf("");
         if (a.out_hist)
             for (int k = tid; k < a.steps; k += blockDim.x) a.out_hist[(size_t)h * a.steps + k] = __builtin_nanf("");
         return;
     }
-    const float* tab = a.table + (size_t)img * table_image_elems(V, HW);
-    const int vg_n = (V + 3) >> 2;
+    const int vg_n = a.table_vg;
+    const float* tab = a.table + (size_t)img * ((size_t)((HW + kTabTile - 1) >> kTabShift) * vg_n * kTabTile * 4);
     const float* clu = a.clu + (size_t)img * HW;
-    solve_prologue(a.rc, s);
+    solve_prologue(rc, s);
     if (PARTIAL) {
         for (int k = tid; k < a.nvb; k += blockDim.x) {
             const int32_t* r = a.ranges + ((size_t)img * a.nvb + k) * 2;
@@ -966,7 +1046,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 
     // Adam's per-step constants (torch single-tensor path: bias corrections and step size in double, then
     // cast): step_size = -lr_k / (1 - beta1^(k+1)), sqrt(1 - beta2^(k+1)); lr_k follows the exponential schedule.
-    float2* sched = (float2*)(smem + a.rc.L.sched);
+    float2* sched = (float2*)(smem + rc.L.sched);
     for (int k = tid; k < min(a.steps, kSchedSteps); k += blockDim.x) {
         const double lr_k = a.lr * (a.lr_every > 0 ? pow(a.gamma, (double)(k / a.lr_every)) : 1.0);
         const double bc1 = 1.0 - pow(a.beta1, (double)(k + 1)), bc2 = 1.0 - pow(a.beta2, (double)(k + 1));
@@ -1018,7 +1098,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     // value is mirrored in os->P for the other readers (flow warp, final output).
     float Pk = tid < 6 ? os->P[tid] : 0.0f, mom1 = 0.0f, mom2 = 0.0f;
     const float fHW = (float)HW;
-    const unsigned int fmask = (1u << a.rc.face_bits) - 1u;
+    const unsigned int fmask = (1u << rc.face_bits) - 1u;
     (void)fmask;
     // world vertices of this thread, resident in registers when the mesh is small enough
     const bool verts_resident = V <= kVertsPerThread * (int)blockDim.x;
@@ -1027,7 +1107,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     for (int k = 0; k < kVertsPerThread; ++k) {
         const int v = tid + k * blockDim.x;
         const bool ok = verts_resident && v < V;
-        wv[k][0] = ok ? a.rc.verts[3 * v] : 0.0f; wv[k][1] = ok ? a.rc.verts[3 * v + 1] : 0.0f; wv[k][2] = ok ? a.rc.verts[3 * v + 2] : 0.0f;
+        wv[k][0] = ok ? rc.verts[3 * v] : 0.0f; wv[k][1] = ok ? rc.verts[3 * v + 1] : 0.0f; wv[k][2] = ok ? rc.verts[3 * v + 2] : 0.0f;
     }
 #ifdef NEMO_STAMPS
     long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1043,27 +1123,27 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
             for (int k = 0; k < 6; ++k) P[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pk), k));
             if (tid == 0) {
-                pose_setup<false>(a.rc.cc, P, P[3], WARP ? a.def_px : P[4], WARP ? a.def_py : P[5], s.pc);
+                pose_setup<false>(rc.cc, P, P[3], WARP ? a.def_px : P[4], WARP ? a.def_py : P[5], s.pc);
                 // back faces may be skipped while the camera is outside the solid (outside its bounding box, with a margin)
                 bool outside = false;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float m = 1e-3f * (a.rc.aabb[3 + k] - a.rc.aabb[k]) + 1e-6f;
-                    outside = outside || P[k] < a.rc.aabb[k] - m || P[k] > a.rc.aabb[3 + k] + m;
+                    const float m = 1e-3f * (rc.aabb[3 + k] - rc.aabb[k]) + 1e-6f;
+                    outside = outside || P[k] < rc.aabb[k] - m || P[k] > rc.aabb[3 + k] + m;
                 }
-                s.pc->cull = a.rc.outward && outside;
+                s.pc->cull = rc.outward && outside;
                 // depth range of the keys: the vertices lie within the bounding radius of the mesh origin, whose view depth is T_z
-                const float z0 = s.pc->T[2] - a.rc.depth_margin;
+                const float z0 = s.pc->T[2] - rc.depth_margin;
                 s.pc->qz0 = z0;
-                s.pc->qc = 8388608.0f - z0 * a.rc.depth_scale;
+                s.pc->qc = 8388608.0f - z0 * rc.depth_scale;
             }
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         STAMP(0);
-        if (verts_resident) project_vertices_resident(a.rc, s, wv); else project_vertices(a.rc, s);
+        if (verts_resident) project_vertices_resident(rc, s, wv); else project_vertices(rc, s);
         STAMP(1);
-        raster_direct<FL, PARTIAL>(a.rc, s);
+        raster_direct<FL, PARTIAL>(rc, s);
 #ifdef NEMO_STAMPS_P1
         if (tid == 0 && a.out_hist) for (int k = 0; k < 6; ++k) a.out_hist[(size_t)h * a.steps + 16 + k] += s.tot[k] / (float)a.steps;
 #endif
@@ -1094,8 +1174,8 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             for (int i = 0; i < 9; ++i) acc.M[i] = 0.f;
             acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
             float dmax = 0.0f, dbox = 0.0f, gfx = 0.0f, gfy = 0.0f;
-            const ViewInv vinv = view_inv(a.rc.cc, s);
-            const float cam_a = a.rc.cc.a;
+            const ViewInv vinv = view_inv(rc.cc, s);
+            const float cam_a = rc.cc.a;
             for (int pt = tid; pt < HW; pt += blockDim.x) {
                 const int yt = pt / W, xt = pt - yt * W;
                 const float lx = xt < W / 2 ? -1.0f + stepx * (float)xt : 1.0f - stepx * (float)(W - 1 - xt);
@@ -1119,9 +1199,9 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (key[k] == kEmptyKey32) continue;    // a source of weight 0 still enters the flow gradient
-                    load_face2<FL>(a.rc, s, (int)(key[k] & fmask), &vi[k][0], &vi[k][1], &vi[k][2]);
+                    load_face2<FL>(rc, s, (int)(key[k] & fmask), &vi[k][0], &vi[k][1], &vi[k][2]);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) dd[k][i] = tab[table_offset(vg_n, vi[k][i], pt)];
+                    for (int i = 0; i < 3; ++i) dd[k][i] = tab[table_offset(vg_n, vbase + vi[k][i], pt)];
                     sk[k] = pixel_score(s.verts[vi[k][0]], s.verts[vi[k][1]], s.verts[vi[k][2]], s.xs[qx[k]], s.ys[qy[k]], dd[k]);
                 }
                 const float obj = (wq[0] * sk[0] + wq[1] * sk[1]) + (wq[2] * sk[2] + wq[3] * sk[3]);
@@ -1146,7 +1226,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             vals[12] = gfx * a.inv_tscale; vals[13] = gfy * a.inv_tscale; vals[14] = dmax; vals[15] = dbox;
         } else {
         int first_chunk;
-        const int cnt = compact_covered32(a.rc, s, row0, row1, &first_chunk);
+        const int cnt = compact_covered32(rc, s, row0, row1, &first_chunk);
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
 #endif
@@ -1159,15 +1239,15 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             acc.S[0] = acc.S[1] = acc.S[2] = 0.f; acc.gbx = acc.gby = 0.f;
             float dmax = 0.0f;      // sum over covered pixels of max(obj, clu) - max(0, clu)
             float dbox = 0.0f;      // the same over the score crop (last step only)
-            const ViewInv vinv = view_inv(a.rc.cc, s);
+            const ViewInv vinv = view_inv(rc.cc, s);
             // The covered entries of this wave, UNR per lane at a time, as straight-line code: the LDS
             // reads, the table / clutter gathers and the arithmetic of the UNR entries interleave.  A lane
             // whose batch runs past the end re-reads its first entry with weight 0.
             constexpr int UNR = 1;
-            const float cam_a = a.rc.cc.a;
+            const float cam_a = rc.cc.a;
             static_assert(UNR == 1, "the entry slots are walked one chunk per trip");
             unsigned int* slot = s.zkey + first_chunk * 64 + (tid & 63);        // entry j of this wave: chunk first_chunk + (j >> 6) * waves
-            const int slot_step = 64 * a.rc.L.waves;
+            const int slot_step = 64 * rc.L.waves;
             for (int ib = tid & 63; ib < cnt; ib += 64 * UNR, slot += slot_step) {
                 int px[UNR], py[UNR], vi[UNR][3];
                 float dd[UNR][3], cc_[UNR], wg[UNR];
@@ -1177,14 +1257,14 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     int f;
                     unpack_entry(*slot, &px[u], &py[u], &f);
                     *slot = kEmptyKey32;                 // the slot is a key again: empty for the next step
-                    load_face2<FL>(a.rc, s, f, &vi[u][0], &vi[u][1], &vi[u][2]);
+                    load_face2<FL>(rc, s, f, &vi[u][0], &vi[u][1], &vi[u][2]);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int p = py[u] * W + px[u];
-                    dd[u][0] = tab[table_offset(vg_n, vi[u][0], p)];
-                    dd[u][1] = tab[table_offset(vg_n, vi[u][1], p)];
-                    dd[u][2] = tab[table_offset(vg_n, vi[u][2], p)];
+                    dd[u][0] = tab[table_offset(vg_n, vbase + vi[u][0], p)];
+                    dd[u][1] = tab[table_offset(vg_n, vbase + vi[u][1], p)];
+                    dd[u][2] = tab[table_offset(vg_n, vbase + vi[u][2], p)];
                     cc_[u] = clu[p];
                 }
 #pragma unroll
@@ -1225,7 +1305,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     if (last) os->last_loss = a.score_boxes ? 1.0f - ((os->box_max + s.tot[15]) / os->box_n - os->box_clu / os->box_n) : loss;
                     if (a.out_hist) a.out_hist[(size_t)h * a.steps + step] = loss;
                 }
-                pose_backward<false>(a.rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
+                pose_backward<false>(rc.cc, *s.pc, s.tot, s.tot + 9, s.tot[12], s.tot[13], g, &g[3], &g[4], &g[5]);
                 if (WARP) { g[4] = s.tot[12]; g[5] = s.tot[13]; }       // the flow's own gradient
             }
             float gk = 0.0f;
@@ -1269,7 +1349,8 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* table,
                       const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
                       const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
                       int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
-                      const int32_t* table_ranges, int32_t* miss_flags, const int32_t* only, void* stream) {
+                      const int32_t* table_ranges, int32_t* miss_flags, const int32_t* only, const int32_t* hyp_to_part,
+                      void* stream) {
     if (n_hyp == 0) return NEMO_OK;
     if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
         return fail(NEMO_ERR_INVALID, "nemo_solve: bad argument");
@@ -1282,8 +1363,19 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* table,
     a.rc.outward = m->faces_outward != nullptr;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
+    // LDS plan: for the whole handle, or for its largest part when every hypothesis renders one part
+    int lay_v = m->V, lay_f = m->F;
+    a.parts = nullptr; a.hyp_to_part = nullptr; a.n_parts = 1;
+    if (hyp_to_part) {
+        if (m->parts.empty()) return fail(NEMO_ERR_STATE, "nemo_solve_parts: the mesh has no parts (call nemo_mesh_set_parts)");
+        if (table_ranges || only) return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_parts: not available with partial tables");
+        lay_v = lay_f = 0;
+        for (const nemo::MeshPart& q : m->parts) { lay_v = q.nv > lay_v ? q.nv : lay_v; lay_f = q.nf > lay_f ? q.nf : lay_f; }
+        a.parts = m->d_parts; a.hyp_to_part = hyp_to_part; a.n_parts = (int)m->parts.size();
+    }
+    int rcode = plan_solve(cam->H, cam->W, lay_v, lay_f, kSolveThreads, m->aabb, &a.rc);
     if (rcode) return rcode;
+    a.table_vg = (m->V + 3) >> 2;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_principal;
     a.score_boxes = score_boxes;
@@ -1316,7 +1408,17 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
                           int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
                           void* stream) {
     return solve_impl(m, cam, table, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
-                      global_batch, dof, opt, out_pose, out_hist, nullptr, nullptr, nullptr, stream);
+                      global_batch, dof, opt, out_pose, out_hist, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int nemo_solve_parts(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+                                const int32_t* hyp_to_image, const int32_t* hyp_to_part, const float* init_campos,
+                                const float* init_theta, const float* init_principal, const int32_t* score_boxes, int32_t n_hyp,
+                                int32_t n_img, int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose,
+                                float* out_hist, void* stream) {
+    if (!hyp_to_part) return fail(NEMO_ERR_INVALID, "nemo_solve_parts: hyp_to_part is required (nemo_solve renders the whole handle)");
+    return solve_impl(m, cam, table, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
+                      global_batch, dof, opt, out_pose, out_hist, nullptr, nullptr, nullptr, hyp_to_part, stream);
 }
 
 extern "C" int nemo_solve_partial(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
@@ -1326,7 +1428,7 @@ extern "C" int nemo_solve_partial(nemo_mesh_t m, const nemo_camera* cam, const f
                                   const int32_t* only_flagged, float* out_pose, float* out_hist, void* stream) {
     if (!table_ranges && !only_flagged) return fail(NEMO_ERR_INVALID, "nemo_solve_partial: table_ranges or only_flagged");
     return solve_impl(m, cam, table, clu, nullptr, init_campos, init_theta, init_principal, score_boxes, n_img, n_img, global_batch,
-                      dof, opt, out_pose, out_hist, table_ranges, miss_flags, only_flagged, stream);
+                      dof, opt, out_pose, out_hist, table_ranges, miss_flags, only_flagged, nullptr, stream);
 }
 
 // Refinement of the keypoint-initialised solver (solve_pose.py:220-324): every proposal of an image is one
@@ -1351,6 +1453,7 @@ extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const floa
     if (rcode) return rcode;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
     a.ranges = nullptr; a.miss = nullptr; a.only = nullptr; a.nvb = 0;
+    a.parts = nullptr; a.hyp_to_part = nullptr; a.n_parts = 1; a.table_vg = (m->V + 3) >> 2;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_flow;
     a.score_boxes = nullptr;
     a.def_px = cam->px; a.def_py = cam->py;

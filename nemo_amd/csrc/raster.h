@@ -127,9 +127,19 @@ inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds
     return L;
 }
 
+// One mesh of a handle that holds several meshes back to back (a multi-class bank): vertices [v0, v0 + nv), faces
+// [f0, f0 + nf) whose indices all lie in that vertex range, and the per-mesh constants of the optimisation loop.
+struct MeshPart {
+    int v0, nv, f0, nf;
+    float aabb[6];
+    float depth_margin, depth_scale, depth_qmax;
+    int face_bits;
+};
+
 struct RasterCtx {
-    const float* verts;
-    const int32_t* faces;
+    const float* verts;         // first vertex of the mesh (or of the part) that is rasterised
+    const int32_t* faces;       // its faces; their vertex indices count from vertex `vbase` of the handle
+    int vbase = 0;              // subtracted from every face index (0 unless a part of a larger handle is rasterised)
     int V, F;
     int outward;                // faces are wound counter-clockwise seen from outside a closed solid (optimisation loop only)
     float aabb[6];              // bounding box of the vertices
@@ -245,7 +255,8 @@ __device__ inline void solve_prologue(const RasterCtx& rc, const Lds& s) {
     for (int i = threadIdx.x; i < H; i += blockDim.x) s.ys[i] = pix_to_ndc(H - 1 - i, H, W);
     if (s.faces2)
         for (int i = threadIdx.x; i < rc.F; i += blockDim.x)
-            s.faces2[i] = make_uint2((unsigned)rc.faces[3 * i] | ((unsigned)rc.faces[3 * i + 1] << 16), (unsigned)rc.faces[3 * i + 2]);
+            s.faces2[i] = make_uint2((unsigned)(rc.faces[3 * i] - rc.vbase) | ((unsigned)(rc.faces[3 * i + 1] - rc.vbase) << 16),
+                                     (unsigned)(rc.faces[3 * i + 2] - rc.vbase));
     const int slots = ((H * W + 63) >> 6) << 6;
     for (int p = threadIdx.x; p < slots; p += blockDim.x) s.zkey[p] = kEmptyKey32;
     if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
@@ -256,7 +267,7 @@ __device__ inline void solve_prologue(const RasterCtx& rc, const Lds& s) {
 template <bool FACES_LDS>
 __device__ inline void load_face2(const RasterCtx& rc, const Lds& s, int f, int* i0, int* i1, int* i2) {
     if (FACES_LDS) { const uint2 t = s.faces2[f]; *i0 = t.x & 0xFFFFu; *i1 = t.x >> 16; *i2 = t.y; }
-    else { *i0 = rc.faces[3 * f + 0]; *i1 = rc.faces[3 * f + 1]; *i2 = rc.faces[3 * f + 2]; }
+    else { *i0 = rc.faces[3 * f + 0] - rc.vbase; *i1 = rc.faces[3 * f + 1] - rc.vbase; *i2 = rc.faces[3 * f + 2] - rc.vbase; }
 }
 
 template <bool FACES_LDS>

@@ -1,13 +1,13 @@
-"""FeatureBankNeMo - the vertex / clutter feature memory (reference nemo/models/feature_banks.py:133-232).
+"""FeatureBankNeMo - the vertex / clutter feature memory (reference nemo/models/feature_banks.py:133-232) and the
+loss-weight builder MaskCreater (:39-130).
 
-At inference the bank is a data container: `memory` = cat(memory_pos [V_total, C], memory_neg
-[num_noise * max_groups, C]); a multi-class bank is the concatenation of the per-mesh vertex blocks
-(offsets = exclusive cumulative sum of mesh_n_list).  The constructor signature and attribute names are
-the reference's.  forward() is the training-time similarity + momentum update (:164-228): the matrix
-products and the momentum blend are torch calls as in the reference, the multi-class gather of the vertex
-features into bank order (`object_labels` given) runs on the HIP replacement of the reference's CuNeMo
-extension (cu_nemo.gather_features).  MaskCreater (:39-130) builds the loss-weight matrices; its
-multi-object branch uses cu_nemo.get_mask.
+At inference the bank is a container: `memory` = [memory_pos (V_total rows) ; memory_neg (clutter rows)], and a
+multi-class bank is the per-mesh vertex blocks back to back (block i starts at the sum of the vertex counts before
+it, the layout cu_layers/CuNeMo/gather_features.py:31 assumes).  `mesh_offsets` / `vertex_block` / `load_memory`
+give the pose solver what it needs.  Constructor signature, attribute names and the return values of forward /
+__call__ are the reference's (they are the drop-in boundary); the bodies are written for this package: the
+clutter ring buffer is a slice assignment, the weight matrices come from one `torch.where`, and the multi-class
+gather runs on the HIP replacement of the reference's CuNeMo extension (cu_nemo.gather_features / get_mask).
 """
 import math
 
@@ -17,145 +17,177 @@ import torch.nn.functional as F
 
 from .cu_nemo import gather_features, get_mask
 
+_DEFAULT_KAPPAS = {"pos": 0, "near": 1e5, "clutter": 5, "class": 1e5}
+
+
+def _pair_weights(points, dist_thr, w_pos, w_near):
+    """[..., K, 3 or 2] point sets -> [..., K, K] weights: w_pos on the diagonal, w_near for pairs no farther
+    apart than dist_thr, 0 elsewhere."""
+    gap = torch.linalg.vector_norm(points.unsqueeze(-2) - points.unsqueeze(-3), dim=-1)
+    k = points.shape[-2]
+    same = torch.eye(k, dtype=torch.bool, device=points.device).expand(gap.shape)
+    zero = torch.zeros((), dtype=torch.float32, device=points.device)
+    near = torch.where(gap <= dist_thr, zero + float(w_near), zero)
+    return torch.where(same, zero + float(w_pos), near)
+
 
 class MaskCreater:
-    """Loss-weight matrices of the vertex / clutter contrastive loss (reference feature_banks.py:39-130):
-    per selected vertex slot a row over [all bank vertices | n_noise clutter rows] holding kappa_pos on the
-    vertex itself, kappa_near on vertices closer than dist_thr, kappa_class on other meshes' vertices and
-    kappa_clutter on the clutter rows."""
+    """Weights of the contrastive vertex loss: for every selected vertex slot one row over
+    [every bank vertex | n_noise clutter rows].
+
+    One mesh per image (sample_indexs is None): row = [pair weights of that vertex | kappa_clutter ...], from the mesh
+    geometry given at construction (`verts_ori`, with dtype_template giving the batch size) or from per-image
+    keypoint positions `kps`.  Several meshes per batch (sample_indexs given): the pair weights of the slot's own mesh
+    sit at that mesh's bank columns, kappa_class on the other meshes' columns, kappa_clutter on the clutter columns
+    (cu_nemo.get_mask).  Returns (weights, bank row of every selected slot)."""
 
     def __init__(self, dist_thr, kappas, n_noise, verts_ori=None, device="cpu"):
-        if verts_ori is not None:
-            assert isinstance(verts_ori, list)
-            with torch.no_grad():
-                vmax = max(v.shape[0] for v in verts_ori)
-                self.vert_sum_num = sum(v.shape[0] for v in verts_ori)
-                dists = []
-                for vv in verts_ori:
-                    padded = torch.cat([vv, torch.zeros((vmax - vv.shape[0], 3), dtype=vv.dtype, device=vv.device)], dim=0)
-                    dists.append((padded[:, None] - padded[None]).pow(2).sum(-1).pow(.5))
-                vert_dists = torch.stack(dists)
-            self.verts_dist_weight = (vert_dists <= dist_thr).to(device).type(torch.float32) * kappas["near"] + \
-                torch.eye(vmax).to(device).type(torch.float32).unsqueeze(dim=0) * (kappas["pos"] - kappas["near"])
-            self.mesh_n_list = [v.shape[0] for v in verts_ori]
-        else:
-            self.verts_dist_weight = None
-        self.kappas = {"pos": 0, "near": 1e5, "clutter": 5, "class": 1e5}
+        self.kappas = dict(_DEFAULT_KAPPAS)
         self.kappas.update(kappas)
         self.dist_thr, self.n_noise, self.device = dist_thr, n_noise, device
+        self.verts_dist_weight = None
+        if verts_ori is None:
+            return
+        if not isinstance(verts_ori, list):
+            raise TypeError("verts_ori is a list with one [K_i, 3] tensor per mesh")
+        self.mesh_n_list = [int(v.shape[0]) for v in verts_ori]
+        self.vert_sum_num = sum(self.mesh_n_list)
+        widest = max(self.mesh_n_list)
+        with torch.no_grad():
+            padded = torch.zeros(len(verts_ori), widest, 3, dtype=verts_ori[0].dtype)
+            for i, v in enumerate(verts_ori):
+                padded[i, : v.shape[0]] = v.detach().cpu()
+            # kappas as passed (not the defaults): the reference builds the stored matrix before merging them
+            self.verts_dist_weight = _pair_weights(padded.float(), dist_thr, kappas["pos"], kappas["near"]).to(device)
+
+    def _single_mesh_rows(self, pair_w, vis_mask, dtype_template):
+        if pair_w.dim() == 2:
+            pair_w = pair_w[None]
+        n_set, k = pair_w.shape[0], pair_w.shape[1]
+        clutter_cols = pair_w.new_full((n_set, k, self.n_noise), float(self.kappas["clutter"]))
+        rows = torch.cat([pair_w, clutter_cols], dim=2)
+        if n_set == 1:
+            if dtype_template is None:
+                raise ValueError("dtype_template gives the batch size when one mesh serves every image")
+            n_set = dtype_template.shape[0]
+            rows = rows.expand(n_set, -1, -1).contiguous()
+        labels = torch.arange(k, device=self.device, dtype=torch.long).repeat(n_set, 1)
+        if vis_mask is None:
+            return rows.view(-1), labels.view(-1)
+        return rows[vis_mask], labels[vis_mask]
 
     def __call__(self, sample_indexs=None, K_padded=None, vis_mask=None, kps=None, dtype_template=None):
-        if kps is not None:
-            vert_dists = (kps[:, None] - kps[:, :, None]).pow(2).sum(-1).pow(.5)
-            verts_dist_weight = (vert_dists <= self.dist_thr).to(self.device).type(torch.float32) * self.kappas["near"] + \
-                torch.eye(kps.shape[1]).to(self.device).type(torch.float32).unsqueeze(dim=0) * (self.kappas["pos"] - self.kappas["near"])
+        if kps is None:
+            pair_w = self.verts_dist_weight
         else:
-            verts_dist_weight = self.verts_dist_weight
-        if sample_indexs is None:                       # one object per image: pose loss only
-            if verts_dist_weight.dim() == 2:
-                verts_dist_weight = verts_dist_weight[None]
-            get = torch.cat([verts_dist_weight, torch.ones(verts_dist_weight.shape[0:2] + (self.n_noise,),
-                                                           device=verts_dist_weight.device) * self.kappas["clutter"]], dim=2)
-            if get.shape[0] == 1:
-                assert dtype_template is not None
-                b_ = dtype_template.shape[0]
-                get = get.expand(b_, -1, -1).contiguous()
-            else:
-                b_ = get.shape[0]
-            vert_index = torch.arange(verts_dist_weight.shape[1], device=self.device)[None].long().expand(b_, -1).contiguous()
-            if vis_mask is not None:
-                return get[vis_mask], vert_index[vis_mask]
-            return get.view(-1), vert_index.view(-1)
-        assert kps is None, "several objects per image: only the mesh-distance weights are supported"
-        if sample_indexs.dim() == 1:
-            sample_indexs = sample_indexs[:, None]
+            pair_w = _pair_weights(kps.float(), self.dist_thr, self.kappas["pos"], self.kappas["near"]).to(self.device)
+        if sample_indexs is None:
+            return self._single_mesh_rows(pair_w, vis_mask, dtype_template)
+        if kps is not None:
+            raise NotImplementedError("several meshes per batch: only the mesh-geometry weights are supported")
         if K_padded is None:
-            assert dtype_template is not None
+            if dtype_template is None:
+                raise ValueError("K_padded or dtype_template is required")
             K_padded = dtype_template.shape[1]
-        total_size = self.vert_sum_num + self.n_noise
-        return get_mask(verts_dist_weight, sample_indexs, self.mesh_n_list, total_size, K_padded, self.kappas["class"],
+        idx = sample_indexs if sample_indexs.dim() == 2 else sample_indexs[:, None]
+        return get_mask(pair_w, idx, self.mesh_n_list, self.vert_sum_num + self.n_noise, K_padded, self.kappas["class"],
                         self.kappas["clutter"], mask_sel=vis_mask, n_noise=self.n_noise)
 
 
 class FeatureBankNeMo(nn.Module):
     def __init__(self, input_size, num_pos, num_noise=-1, max_groups=-1, momentum=0.5, **kwargs):
         super().__init__()
-        stdv = 1.0 / math.sqrt(input_size / 3)
-        self.memory_pos = torch.rand(num_pos, input_size).mul_(2 * stdv).add_(-stdv)
-        self.memory_neg = torch.rand(num_noise * max_groups if max_groups > 0 else 0, input_size).mul_(2 * stdv).add_(-stdv)
-        self.memory_pos.requires_grad = False
-        self.memory_neg.requires_grad = False
+        bound = 1.0 / math.sqrt(input_size / 3)
+        n_neg = num_noise * max_groups if max_groups > 0 else 0
+        self.memory_pos = torch.empty(num_pos, input_size).uniform_(-bound, bound)
+        self.memory_neg = torch.empty(n_neg, input_size).uniform_(-bound, bound)
         self.num_noise = num_noise
-        self.lru = 0
         self.max_lru = max_groups if max_groups > 0 else -1
-        self.kwargs = kwargs
+        self.lru = 0                      # image slot of the clutter ring buffer that is written next
         self.momentum = momentum
+        self.kwargs = kwargs              # mesh_n_list: vertex count of every mesh of a multi-class bank
 
+    # ---- container ----
     @property
     def memory(self):
         return torch.cat((self.memory_pos, self.memory_neg), dim=0)
 
     def mesh_offsets(self):
-        """Start row of every mesh's vertex block in memory_pos (multi-class layout)."""
-        n_list = self.kwargs.get("mesh_n_list")
-        if n_list is None:
+        """First memory_pos row of every mesh (multi-class layout: blocks back to back)."""
+        counts = self.kwargs.get("mesh_n_list")
+        if counts is None:
             return [0]
-        out, acc = [], 0
-        for n in n_list:
-            out.append(acc)
-            acc += int(n)
-        return out
+        starts = [0]
+        for n in list(counts)[:-1]:
+            starts.append(starts[-1] + int(n))
+        return starts
 
     def vertex_block(self, mesh_index=0):
-        """memory rows of one mesh ([V_mesh, C])."""
-        n_list = self.kwargs.get("mesh_n_list")
-        if n_list is None:
+        """memory_pos rows of one mesh, [V_mesh, C]."""
+        counts = self.kwargs.get("mesh_n_list")
+        if counts is None:
             return self.memory_pos
-        lo = self.mesh_offsets()[mesh_index]
-        return self.memory_pos[lo:lo + int(n_list[mesh_index])]
+        first = self.mesh_offsets()[mesh_index]
+        return self.memory_pos[first:first + int(counts[mesh_index])]
 
     def load_memory(self, memory):
-        """Fill the bank from a checkpoint's `memory` tensor (rows [0:V] vertices, the rest clutter)."""
-        v = self.memory_pos.shape[0]
-        self.memory_pos = memory[:v].detach().clone().to(self.memory_pos.device)
-        self.memory_neg = memory[v:].detach().clone().to(self.memory_pos.device)
+        """Fill the bank from a checkpoint's `memory` tensor: rows [0, V_total) vertices, the rest clutter."""
+        n_pos = self.memory_pos.shape[0]
+        dev = self.memory_pos.device
+        self.memory_pos = memory[:n_pos].detach().clone().to(dev)
+        self.memory_neg = memory[n_pos:].detach().clone().to(dev)
         return self
 
     def to(self, device):
-        self.memory_pos = self.memory_pos.to(device)
-        self.memory_neg = self.memory_neg.to(device)
+        self.memory_pos, self.memory_neg = self.memory_pos.to(device), self.memory_neg.to(device)
         return self
 
     def cuda(self, device=None):
         return self.to("cuda" if device is None else device)
 
-    def forward(self, x, visible, x_to_bank=None, object_labels=None, vis_mask=None):
+    # ---- training-time update (reference :165-222) ----
+    def _vertex_and_clutter_rows(self, x):
         if self.num_noise == 0:
-            t_, noise_similarity = x, torch.zeros(1)
-        else:
-            t_ = x[:, 0:(x.shape[1] - self.num_noise), :]
-            noise_similarity = torch.matmul(x[:, -self.num_noise:, :], self.memory_pos.t())
-        similarity = torch.matmul(t_.view(-1) if vis_mask is None else t_[vis_mask], self.memory.t())
+            return x, None
+        k = x.shape[1] - self.num_noise
+        return x[:, :k], x[:, k:]
+
+    def _bank_target(self, feats, visible, object_labels):
+        """Per bank row the batch-averaged visible feature that the momentum update blends in."""
+        if feats.dim() != 3:
+            return feats                                    # the caller already reduced it to [V_total, C]
+        n_img = feats.shape[0]
+        if object_labels is None:
+            return (feats * visible.to(feats.dtype).unsqueeze(-1)).sum(dim=0) / n_img
+        summed, _ = gather_features(feats, weights=visible.to(torch.float32), sample_indexs=object_labels.to(torch.int32),
+                                    mesh_n_list=self.kwargs.get("mesh_n_list"))
+        return summed / n_img
+
+    def _store_clutter(self, clutter_rows):
+        """Ring buffer of max_lru images x num_noise rows: the batch's rows go to image slot `lru` onwards; rows
+        that would run past the end of the buffer are dropped (no wrap within one batch)."""
+        new = clutter_rows.reshape(-1, clutter_rows.shape[-1])
+        cap = self.memory_neg.shape[0]
+        start = 0 if new.shape[0] > cap else self.lru * self.num_noise
+        fits = max(min(new.shape[0], cap - start), 0)
+        buf = self.memory_neg.clone()
+        buf[start:start + fits] = new[:fits]
+        self.memory_neg = buf
+
+    def forward(self, x, visible, x_to_bank=None, object_labels=None, vis_mask=None):
+        """x [B, K (+ num_noise), C] vertex (+ clutter) features, visible [B, K].
+        -> (similarity of the selected vertex features with every bank row, similarity of the clutter features with
+        the vertex rows); the bank is then updated without gradient: momentum blend + re-normalisation of the vertex
+        rows, clutter rows into the ring buffer."""
+        vert_feats, clutter_feats = self._vertex_and_clutter_rows(x)
+        noise_similarity = torch.zeros(1) if clutter_feats is None else clutter_feats @ self.memory_pos.T
+        picked = vert_feats.view(-1) if vis_mask is None else vert_feats[vis_mask]
+        similarity = picked @ self.memory.T
         with torch.no_grad():
-            if x_to_bank is None:
-                x_to_bank = x[:, 0:(x.shape[1] - self.num_noise), :]
-            b_ = x_to_bank.shape[0]
-            if x_to_bank.dim() == 3:
-                if object_labels is None:
-                    x_to_bank = torch.mean(x_to_bank * visible.type(x.dtype)[..., None], dim=0)
-                else:       # several meshes in the batch: visible vertex features summed into bank order
-                    x_to_bank, _ = gather_features(x_to_bank, weights=visible.type(torch.float32),
-                                                   sample_indexs=object_labels.type(torch.int32),
-                                                   mesh_n_list=self.kwargs.get("mesh_n_list"))
-                    x_to_bank = x_to_bank / b_
-            self.memory_pos = F.normalize(self.memory_pos * self.momentum + x_to_bank * (1 - self.momentum), dim=1, p=2)
-            if self.num_noise > 0:
-                new = x[:, -self.num_noise:, :].contiguous().view(-1, x.shape[2])
-                if x.shape[0] * self.num_noise > self.memory_neg.shape[0]:
-                    self.memory_neg = new[0:self.memory_neg.shape[0]]
-                else:
-                    self.memory_neg = torch.cat([self.memory_neg[0:self.lru * self.num_noise], new,
-                                                 self.memory_neg[(self.lru + x.shape[0]) * self.num_noise:]],
-                                                dim=0)[:self.max_lru * self.num_noise]
+            target = self._bank_target(vert_feats if x_to_bank is None else x_to_bank, visible, object_labels)
+            blended = self.momentum * self.memory_pos + (1.0 - self.momentum) * target
+            self.memory_pos = F.normalize(blended, p=2, dim=1)
+            if clutter_feats is not None:
+                self._store_clutter(clutter_feats)
             self.lru = (self.lru + x.shape[0]) % self.max_lru
         return similarity, noise_similarity

@@ -53,6 +53,19 @@ class MeshHandle:
             torch.cuda.current_stream().synchronize()   # `mem` may be a temporary
         self.C = mem.shape[1]
 
+    def set_parts(self, vert_counts, face_counts):
+        """Names the meshes of a handle built from several meshes back to back (a multi-class bank): part l is the
+        next vert_counts[l] vertices and face_counts[l] faces.  solve(..., hyp_to_part=...) then renders one part per
+        hypothesis."""
+        lib = _lib.load()
+        vc, fc = [int(x) for x in vert_counts], [int(x) for x in face_counts]
+        if len(vc) != len(fc) or not vc:
+            raise ValueError("vert_counts and face_counts need one entry per mesh")
+        arr = C.c_int32 * len(vc)
+        with torch.cuda.device(self.device):
+            check(lib.nemo_mesh_set_parts(self.h, arr(*vc), arr(*fc), len(vc)), "nemo_mesh_set_parts")
+        self.part_verts, self.part_faces = vc, fc
+
     @property
     def h(self):
         if self._h is None:
@@ -375,9 +388,10 @@ def align_maps(maps_source, distance_source, principal_source, target_shape, dis
 
 def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, hyp_to_image=None, global_batch=None,
           dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, lr_gamma=0.2, lr_every=None, history=False,
-          score_boxes=None):
+          score_boxes=None, hyp_to_part=None):
     """Runs the whole Adam loop on device.  -> (pose [n_hyp,8], loss_hist [n_hyp,steps] or None).
-    pose columns: cx, cy, cz, theta, px, py, score (last forward), first-forward loss."""
+    pose columns: cx, cy, cz, theta, px, py, score (last forward), first-forward loss.
+    hyp_to_part [n_hyp] (a handle with set_parts): the mesh every hypothesis renders; None = the whole handle."""
     lib = _lib.load()
     cp, th, pr, n_hyp = _pose_args(init_campos, init_theta, init_principal)
     n_img = table.shape[0]
@@ -397,9 +411,17 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
     if score_boxes is not None:
         boxes = score_boxes.to(device=cp.device, dtype=torch.int32).reshape(n_hyp, 4).contiguous()
     with torch.cuda.device(cp.device):
-        check(lib.nemo_solve(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(cp), ptr(th), ptr(pr),
-                             ptr(boxes, torch.int32), n_hyp, n_img, gb, int(dof), C.byref(opt), ptr(out), ptr(hist),
-                             stream_ptr()), "nemo_solve")
+        if hyp_to_part is not None:
+            h2p = hyp_to_part.to(device=cp.device, dtype=torch.int32).contiguous()
+            if h2p.numel() != n_hyp:
+                raise ValueError("hyp_to_part needs one entry per hypothesis")
+            check(lib.nemo_solve_parts(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(h2p, torch.int32),
+                                       ptr(cp), ptr(th), ptr(pr), ptr(boxes, torch.int32), n_hyp, n_img, gb, int(dof), C.byref(opt),
+                                       ptr(out), ptr(hist), stream_ptr()), "nemo_solve_parts")
+        else:
+            check(lib.nemo_solve(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(h2i, torch.int32), ptr(cp), ptr(th), ptr(pr),
+                                 ptr(boxes, torch.int32), n_hyp, n_img, gb, int(dof), C.byref(opt), ptr(out), ptr(hist),
+                                 stream_ptr()), "nemo_solve")
     return out, hist
 
 

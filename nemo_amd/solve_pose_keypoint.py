@@ -12,8 +12,6 @@ values.  One image at a time (the reference asserts batch size 1, nemo/models/ne
 The local-maximum search restates skimage.feature.peak_local_max (scikit-image 0.19.3, the version
 the reference pins) for the arguments the reference passes: min_distance, exclude_border=False.
 """
-import copy
-import math
 import time
 
 import numpy as np
@@ -95,31 +93,28 @@ def peak_local_max(image, min_distance=1, exclude_border=False):
 
 
 def _proposals(cfg, corr, poses, px_samples, py_samples):
-    """solve_pose.py:161-207: one proposal (pose grid arg-max + translation sample) per retained maximum."""
-    corr2d = corr.reshape(-1, len(px_samples), len(py_samples))
-    corr2d_max = np.max(corr2d, axis=0)
+    """The starting points of the refinement (solve_pose.py:161-207): the correlation volume [pose, px, py] is
+    reduced over poses, the translation samples that are local maxima of that map and reach
+    cfg.inference.pre_rendering_thr are kept (all of them; the single highest positive one when none reaches it),
+    and each kept translation sample is paired with the grid pose that correlates best there.
+    -> (list of dict(azimuth, elevation, theta, distance, px, py, principal), reduced map [n_px, n_py])."""
+    volume = corr.reshape(-1, len(px_samples), len(py_samples))
+    heat = volume.max(axis=0)
     if cfg.inference.search_translation:
-        extrema_2d = peak_local_max(corr2d_max, min_distance=cfg.inference.min_distance, exclude_border=False)
+        peaks = peak_local_max(heat, min_distance=cfg.inference.min_distance, exclude_border=False)
     else:
-        extrema_2d = [[0, 0]]
-    larger, max_e, max_v = [], None, 0
-    for e in extrema_2d:
-        if corr2d_max[e[0], e[1]] >= cfg.inference.pre_rendering_thr:
-            larger.append(e)
-        if corr2d_max[e[0], e[1]] > max_v:
-            max_v = corr2d_max[e[0], e[1]]
-            max_e = e
-    iter_extrema = larger if len(larger) > 0 else [max_e]
-    extrema = []
-    for e in iter_extrema:
-        if e is None:
-            continue
-        c = corr2d[:, e[0], e[1]].reshape(poses.shape[0], poses.shape[1], poses.shape[2], poses.shape[3])
-        ia, ie, it, idist = np.unravel_index(np.argmax(c, axis=None), c.shape)
-        p = poses[ia, ie, it, idist]
-        extrema.append({"azimuth": p[0], "elevation": p[1], "theta": p[2], "distance": p[3], "px": px_samples[e[0]],
-                        "py": py_samples[e[1]], "principal": [px_samples[e[0]], py_samples[e[1]]]})
-    return extrema, corr2d_max
+        peaks = np.zeros((1, 2), dtype=np.int64)
+    height = heat[peaks[:, 0], peaks[:, 1]] if len(peaks) else np.zeros(0, dtype=heat.dtype)
+    chosen = peaks[height >= cfg.inference.pre_rendering_thr]
+    if len(chosen) == 0 and len(peaks) and height.max() > 0:
+        chosen = peaks[int(np.argmax(height))][None]          # argmax returns the first of equal heights
+    flat_poses = poses.reshape(-1, 4)
+    out = []
+    for ix, iy in chosen:
+        azim, elev, theta, dist = flat_poses[int(np.argmax(volume[:, ix, iy]))]
+        out.append({"azimuth": azim, "elevation": elev, "theta": theta, "distance": dist, "px": px_samples[ix],
+                    "py": py_samples[iy], "principal": [px_samples[ix], py_samples[iy]]})
+    return out, heat
 
 
 def solve_pose(cfg, feature_map, inter_module, kp_features, clutter_bank, poses, kp_coords, kp_vis, px_samples=None,
@@ -201,9 +196,16 @@ def solve_pose(cfg, feature_map, inter_module, kp_features, clutter_bank, poses,
         pred["final"] = ret                 # a dict, not a list, exactly as the reference returns it (:329-338)
 
     if debug:
+        # the reference builds these maps from the object score of the LAST forward, i.e. at the parameters before
+        # the final update (:282-290): one step fewer gives exactly those parameters
+        before_last, _ = ops.solve_flow(mesh, inter_module.camera(), table, clutter_score, C0, th0, fl0,
+                                        hyp_to_image=torch.zeros(n, dtype=torch.int32), global_batch=1,
+                                        optimize_translation=cfg.inference.optimize_translation, translation_scale=scale,
+                                        steps=max(int(cfg.inference.epochs) - 1, 0), lr_every=0, **adam)
+        before_last = before_last.cpu()
         seg_maps, score_maps = [], []
         for i in range(n):
-            obj = _object_score_map(inter_module, fm, host[i], scale)
+            obj = _object_score_map(inter_module, fm, before_last[i], scale)
             seg_maps.append(((obj > clutter_score[0]) * (obj > 0.0)).cpu().numpy().astype(np.uint8))
             score_maps.append(obj.cpu().numpy())
         pred["object_idx_map"], pred["seg_maps"] = resolve_occ(np.array(seg_maps), np.array(score_maps))
@@ -224,60 +226,56 @@ def _object_score_map(inter_module, fm, pose_row, scale):
 
 
 def resolve_occ(seg_maps, score_maps):
-    """Pairwise occlusion reasoning between proposals: where two masks overlap, the one with the larger
-    (overlap + half the rest) score keeps the overlap.  -> (object index map, masks)."""
-    seg_maps_copy = copy.deepcopy(seg_maps)
-    n = seg_maps.shape[0]
-    for i in range(n):
-        for j in range(i + 1, n):
-            overlap = (seg_maps[i] == 1) * (seg_maps[j] == 1)
-            if np.sum(overlap) == 0:
+    """Occlusion reasoning between the masks of several proposals (solve_pose.py:350-402).  Every pair of masks that
+    overlap is judged on the ORIGINAL masks: a proposal's claim is its score summed over the overlap plus half its
+    score over the rest of its own mask, and the proposal with the smaller claim (the later one at equal claims)
+    gives the overlap up.  -> (index map: 0 = nobody, k + 1 = proposal k, the first one where several still claim a
+    pixel; the reduced masks)."""
+    masks = np.asarray(seg_maps)
+    scores = np.asarray(score_maps)
+    on = masks == 1
+    total = (masks * scores).reshape(len(masks), -1).sum(axis=1)
+    kept = masks.copy()
+    for first in range(len(masks)):
+        for second in range(first + 1, len(masks)):
+            both = on[first] & on[second]
+            if not both.any():
                 continue
-            score_i = np.sum(overlap * score_maps[i]) + np.sum((seg_maps[i] - overlap) * score_maps[i]) * 0.5
-            score_j = np.sum(overlap * score_maps[j]) + np.sum((seg_maps[j] - overlap) * score_maps[j]) * 0.5
-            if score_i >= score_j:
-                seg_maps_copy[j][overlap == 1] = 0
-            else:
-                seg_maps_copy[i][overlap == 1] = 0
-    pad = np.concatenate([np.zeros((1,) + seg_maps_copy.shape[1:], dtype=seg_maps_copy.dtype), seg_maps_copy], axis=0)
-    return np.argmax(pad, axis=0), seg_maps_copy
+            shared = [float(scores[k][both].sum()) for k in (first, second)]
+            # overlap + half of what is left of the mask (masks are 0 / 1, so mask - overlap is the rest)
+            claim = [shared[0] + 0.5 * (float(total[first]) - shared[0]), shared[1] + 0.5 * (float(total[second]) - shared[1])]
+            loser = second if claim[0] >= claim[1] else first
+            kept[loser][both] = 0
+    layered = np.concatenate([np.zeros_like(kept[:1]), kept], axis=0)
+    return layered.argmax(axis=0), kept
 
 
 # ---------------------------------------------------------------------------------------------
 # projected keypoint coordinates of the pose grid
 # ---------------------------------------------------------------------------------------------
 def pre_compute_kp_coords(mesh_path, azimuth_samples, elevation_samples, theta_samples, distance_samples, viewport=3000):
-    """(poses [A,E,T,D,4] f32, kp_coords [A*E*T*D, V, 2] f32, kp_vis [A*E*T*D, V] f32 (all ones)) in f64
-    arithmetic like the reference.  `mesh_path` is an OFF file or an array of vertices [V,3]."""
-    xvert = load_off(mesh_path)[0] if isinstance(mesh_path, str) else np.asarray(mesh_path)
-    n = len(azimuth_samples) * len(elevation_samples) * len(theta_samples) * len(distance_samples)
-    poses = np.zeros((n, 4), dtype=np.float32)
-    count = 0
-    for azim_ in azimuth_samples:
-        for elev_ in elevation_samples:
-            for theta_ in theta_samples:
-                for dist_ in distance_samples:
-                    poses[count] = [azim_, elev_, theta_, dist_]
-                    count += 1
-    kp_coords = np.zeros((n, len(xvert), 2), dtype=np.float32)
-    kp_vis = np.ones((n, len(xvert)), dtype=np.float32)
-    x3d_h = np.hstack((xvert, np.ones((len(xvert), 1)))).T
-    P = np.array([[viewport, 0, 0], [0, viewport, 0], [0, 0, -1]])
-    for i, (azim_, elev_, theta_, dist_) in enumerate(poses):
-        C = np.zeros((3, 1))
-        C[0] = dist_ * math.cos(elev_) * math.sin(azim_)
-        C[1] = -dist_ * math.cos(elev_) * math.cos(azim_)
-        C[2] = dist_ * math.sin(elev_)
-        azimuth, elevation = -azim_, -(math.pi / 2 - elev_)
-        Rz = np.array([[math.cos(azimuth), -math.sin(azimuth), 0], [math.sin(azimuth), math.cos(azimuth), 0], [0, 0, 1]])
-        Rx = np.array([[1, 0, 0], [0, math.cos(elevation), -math.sin(elevation)], [0, math.sin(elevation), math.cos(elevation)]])
-        R_rot = np.dot(Rx, Rz)
-        R = np.hstack((R_rot, np.dot(-R_rot, C)))
-        x2d = np.dot(P, np.dot(R, x3d_h))
-        x2d = x2d[0:2, :] / x2d[2:3, :]
-        R2d = np.array([[math.cos(theta_), -math.sin(theta_)], [math.sin(theta_), math.cos(theta_)]])
-        x2d = np.dot(R2d, x2d).T
-        x2d[:, 1] *= -1
-        kp_coords[i] = x2d
-    poses = poses.reshape(len(azimuth_samples), len(elevation_samples), len(theta_samples), len(distance_samples), 4)
-    return poses, kp_coords, kp_vis
+    """Image-plane position of every mesh vertex for every pose of the grid (solve_pose.py:405-562):
+    -> (poses [A,E,T,D,4] f32, kp_coords [A*E*T*D, V, 2] f32, kp_vis [A*E*T*D, V] f32, all ones).
+    `mesh_path` is an OFF file or an array of vertices [V,3] in the mesh's own axes (z up, camera circling in the
+    x-y plane).  The reference's chain of rotation matrices is written out in closed form: with
+    right = (cos a, sin a, 0), up = (-sin e sin a, sin e cos a, cos e) and n = (cos e sin a, -cos e cos a, sin e)
+    (the unit vector from the object to the camera, which sits at dist * n), a vertex X lands at
+    (u, w) = viewport * (right.X, up.X) / (dist - n.X), which is then turned by theta in the image plane and
+    flipped in y.  Evaluated in float64 for all poses at once."""
+    xvert = np.asarray(load_off(mesh_path)[0] if isinstance(mesh_path, str) else mesh_path, dtype=np.float64)
+    grid = np.stack(np.meshgrid(np.asarray(azimuth_samples, dtype=np.float64), np.asarray(elevation_samples, dtype=np.float64),
+                                np.asarray(theta_samples, dtype=np.float64), np.asarray(distance_samples, dtype=np.float64),
+                                indexing="ij"), axis=-1)
+    poses = grid.astype(np.float32)                           # the reference keeps the grid in float32 and projects from it
+    a, e, t, d = (poses.reshape(-1, 4)[:, k].astype(np.float64) for k in range(4))
+    sa, ca, se, ce = np.sin(a), np.cos(a), np.sin(e), np.cos(e)
+    zero = np.zeros_like(a)
+    right = np.stack([ca, sa, zero], axis=1)
+    up = np.stack([-se * sa, se * ca, ce], axis=1)
+    toward = np.stack([ce * sa, -ce * ca, se], axis=1)
+    depth = d[:, None] - toward @ xvert.T                     # [n_pose, V]
+    u = viewport * (right @ xvert.T) / depth
+    w = viewport * (up @ xvert.T) / depth
+    st, ct = np.sin(t)[:, None], np.cos(t)[:, None]
+    kp_coords = np.stack([ct * u - st * w, -(st * u + ct * w)], axis=2).astype(np.float32)
+    return poses, kp_coords, np.ones(kp_coords.shape[:2], dtype=np.float32)

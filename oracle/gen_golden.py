@@ -1,6 +1,6 @@
 """Generates the committed fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY.
 
-    python oracle/gen_golden.py [leaf] [small] [full]
+    python oracle/gen_golden.py [leaf] [small] [full] [grid]
 
 leaf   tests/golden/leaf_golden.npz   - outputs of the reference's OWN dependency-free leaf files
        (nemo/utils/general.py, pose.py, features.py, flow_warp.py), loaded standalone from
@@ -9,7 +9,10 @@ leaf   tests/golden/leaf_golden.npz   - outputs of the reference's OWN dependenc
 small  tests/golden/oracle_small.npz  - oracle outputs on a 40x50x32 scene (face-index buffers of the
        144-pose grid, grid losses, a 300-step solve).
 full   tests/golden/oracle_full.npz   - oracle outputs at BASELINE size (80x100x128, V=1118, F=1904):
-       face-index buffers of 8 poses, one image's grid losses, a 2-image 300-step solve.
+       face-index buffers of 8 poses, a 2-image 300-step solve.
+grid   tests/golden/oracle_full_grid.npz - BASELINE-size pose-grid scoring: losses and arg-min of 4 images against
+       the 144-pose grid, the 300-step refinement of the 8 best grid poses of 2 of them (global batch 2), and a
+       6-D slice: 2 off-centre images x the 576-pose grid (4 distances) x 3 principal-point samples.
 
 The render-path fixtures come from the oracle itself (parity with PyTorch3D is unpinned: no PyTorch3D
 here); they freeze the oracle so that a change in its behaviour, or a difference between machines, is
@@ -117,9 +120,56 @@ def gen_full():
     print("oracle_full.npz written")
 
 
+def gen_full_grid():
+    """What the matrix-core scoring instance of the BASELINE size (128 channels, 144 / 576 poses) is checked against."""
+    sc = Scene(80, 100, 128, 1000, 375.0, n_clutter=2560)
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = R.get_pre_render_samples(sc.ref, az, el, th, di)
+    first_seed, B, K = 200, 4, 8
+    fm, _ = sc.feature_maps(B, first_seed)
+    clu = R.clutter_score(fm, sc.clutter)
+    loss = R.grid_losses(maps, fm, clu).T                                   # [B, 144]
+    out = dict(grid_first_seed=np.int64(first_seed), grid_loss=loss.numpy(), grid_argmin=loss.argmin(dim=1).numpy(),
+               grid_map_checksum=maps.double().sum(dim=(1, 2, 3, 4)).numpy())
+    print("3-D grid done", flush=True)
+    # the K best grid poses of images 0 and 1, refined together: every hypothesis sees the loss normaliser of the
+    # 2-image batch (hypotheses are rows of the oracle's batch, global_batch rescales the batch mean)
+    order = torch.sort(loss[:2], dim=1, stable=True)[1][:, :K]               # [2, K]
+    C0, th0 = cs[order].reshape(2 * K, 3), ths[order].reshape(2 * K)
+    Cr, thr, _, scores, hist = R.optimize_poses(sc.ref, fm[:2].repeat_interleave(K, dim=0), clu[:2].repeat_interleave(K, dim=0),
+                                                C0, th0, None, 3, epochs=300, global_batch=2, record=True)
+    out.update(k8_order=order.numpy(), k8_C=Cr.numpy(), k8_theta=thr.numpy(), k8_scores=scores.numpy(),
+               k8_loss_hist=torch.stack([h["per_image"] for h in hist], dim=1).numpy())
+    print("K=8 solve done", flush=True)
+    # 6-D initialisation slice (batch_solve_pose.py:264-295): 576 poses x 3 principal samples x 2 off-centre images
+    az6, el6, th6, di6, _, _ = R.get_param_samples(CFG6D)
+    maps6, cs6, ths6 = R.get_pre_render_samples(sc.ref, az6, el6, th6, di6)
+    cand = torch.tensor([[37.5, 30.0], [50.0, 40.0], [62.5, 50.0]])
+    gt_pr = torch.tensor([[39.0, 31.0], [60.0, 49.0]])
+    fms = []
+    for i in range(2):
+        sc.ref.principal = gt_pr[i:i + 1]
+        fms.append(R.synthetic_feature_map(sc.ref, sc.clutter, 260 + i)[0])
+    sc.ref.principal = None
+    fm6 = torch.stack(fms)
+    clu6 = R.clutter_score(fm6, sc.clutter)
+    ones, centre = torch.ones(2), torch.tensor([[50.0, 40.0]]).expand(2, -1)
+    l6 = []
+    for pr in cand:
+        pr_ = pr[None].expand(2, -1)
+        t_fm = R.align_no_centered(fm6, ones, pr_, (80, 100), ones, centre, padding_mode='border')
+        t_clu = R.align_no_centered(clu6[:, None], ones, pr_, (80, 100), ones, centre, padding_mode='border').squeeze(1)
+        l6.append(R.grid_losses(maps6, t_fm, t_clu).T)
+    l6 = torch.stack(l6)                                                    # [3, 2, 576]
+    out.update(six_first_seed=np.int64(260), six_gt_principal=gt_pr.numpy(), six_candidates=cand.numpy(), six_loss=l6.numpy(),
+               six_argmin=l6.argmin(dim=2).numpy(), six_campos=cs6.numpy(), six_theta=ths6.numpy())
+    np.savez_compressed(os.path.join(GOLD, "oracle_full_grid.npz"), **out)
+    print("oracle_full_grid.npz written")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["leaf", "small", "full"]
+    what = sys.argv[1:] or ["leaf", "small", "full", "grid"]
     torch.set_num_threads(8)
     if "leaf" in what:
         gen_leaf()
@@ -127,3 +177,5 @@ if __name__ == "__main__":
         gen_small()
     if "full" in what:
         gen_full()
+    if "grid" in what:
+        gen_full_grid()

@@ -349,3 +349,24 @@ def test_top_k_grid_poses_are_best_first_and_stable(monkeypatch):
     assert torch.equal(m3, torch.tensor([[0.1, 0.2, 0.2], [0.05, 0.3, 0.3]]))
     with pytest.raises(ValueError):
         bsp.get_init_pos_rendered_dim0(maps, pos, theta, torch.zeros(2, 2, 2, 2), top_k=6)
+
+
+def test_resolve_occ_known_answers():
+    """Two overlapping masks: the one whose (overlap + half the rest) score is larger keeps the overlap; equal
+    claims go to the earlier proposal; disjoint masks are untouched."""
+    from nemo_amd.solve_pose_keypoint import resolve_occ
+    seg = np.zeros((3, 4, 6), dtype=np.uint8)
+    seg[0, :, 0:3] = 1
+    seg[1, :, 2:5] = 1          # overlaps proposal 0 in column 2
+    seg[2, 0, 5] = 1            # disjoint
+    score = np.ones((3, 4, 6), dtype=np.float32)
+    score[1] *= 2.0             # proposal 1 claims more everywhere
+    idx, kept = resolve_occ(seg, score)
+    assert kept[0, :, 2].sum() == 0 and kept[1, :, 2].sum() == 4 and np.array_equal(kept[2], seg[2])
+    assert np.array_equal(kept[0, :, :2], seg[0, :, :2])
+    assert idx[0, 2] == 2 and idx[0, 0] == 1 and idx[0, 5] == 3 and idx[1, 5] == 0
+    # equal claims: the earlier proposal wins the overlap
+    idx2, kept2 = resolve_occ(seg[:2], np.ones((2, 4, 6), dtype=np.float32))
+    assert kept2[0, :, 2].sum() == 4 and kept2[1, :, 2].sum() == 0
+    # the inputs are not modified
+    assert seg[0, :, 2].sum() == 4
