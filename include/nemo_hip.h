@@ -160,7 +160,10 @@ int nemo_grid_score_static(const float* pre, const float* feat, const float* clu
  * order inside the workspace and runs one [N x C].[C x B] product per pixel.  C must be 16, 32, 64 or
  * 128 (nemo_grid_pack_bytes returns 0 otherwise: use nemo_grid_score).
  * packed: device buffer of nemo_grid_pack_bytes(N, C, HW) bytes, filled by nemo_grid_pack.
- * Outputs as nemo_grid_score; workspace of nemo_grid_score_packed_workspace(N, B, C, HW) bytes. */
+ * Outputs as nemo_grid_score; workspace of nemo_grid_score_packed_workspace(N, B, C, HW) bytes.
+ * Input contract of the matrix-core forms (this one, nemo_grid_score_recentred and nemo_similarity_table for 16, 32,
+ * 64 or 128 channels): feature values of magnitude up to 255 (the backbone's maps are unit vectors per pixel,
+ * nemo/models/keypoint_representation_net.py:385-386); larger magnitudes are clamped to that range, NaN stays NaN. */
 size_t nemo_grid_pack_bytes(int32_t N, int32_t C, int32_t HW);
 int nemo_grid_pack(const float* pre, int32_t N, int32_t C, int32_t HW, void* packed, void* stream);
 size_t nemo_grid_score_packed_workspace(int32_t N, int32_t B, int32_t C, int32_t HW);

@@ -57,6 +57,9 @@ struct PoseCam {
     float qz0, qc;               // optimisation loop: start of the quantised depth range, and 2^23 - start in steps
 };
 
+// torch.max(a, b) semantics: NaN if either operand is NaN (fmaxf alone returns the other operand).
+__device__ inline float max_nan(float a, float b) { return __builtin_isunordered(a, b) ? a + b : fmaxf(a, b); }
+
 __device__ inline void normalize3(float x, float y, float z, float* o, float* n_out) {
     float n = sqrtf((x * x + y * y) + z * z);
     n = n > kNormEps ? n : (n != n ? n : kNormEps);
@@ -299,7 +302,8 @@ __device__ inline float pixel_fused(float a, float ia, float bx, float by, const
     const float u0 = e0 * zt0, u1 = e1 * zt1, u2 = e2 * zt2;
     const float inv_su = __builtin_amdgcn_rcpf((u0 + u1) + u2);
     const float obj = ((u0 * d[0] + u1 * d[1]) + u2 * d[2]) * inv_su;
-    const float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+    // sub-gradient of max(obj, cl); a NaN score (or clutter score) poisons the gradient as it does in autograd
+    const float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : (__builtin_isunordered(obj, cl) ? obj + cl : 0.0f));
     const float G = -mk * weight * inv_su;
     const float gu0 = G * (d[0] - obj), gu1 = G * (d[1] - obj), gu2 = G * (d[2] - obj);
     const float ge0 = gu0 * zt0, ge1 = gu1 * zt1, ge2 = gu2 * zt2;

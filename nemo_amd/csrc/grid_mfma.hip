@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
                 S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], S, 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lacc[r][i] += fmaxf(S[i] * unscale, cl);          // cl = -inf without a clutter map
+            for (int i = 0; i < 16; ++i) lacc[r][i] += max_nan(S[i] * unscale, cl);        // cl = -inf without a clutter map
             if (st + 1 < nstage) { if (buf == 0) park(1, qb); else park(0, qa); }
             __syncthreads();
         }

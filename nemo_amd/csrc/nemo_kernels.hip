@@ -705,7 +705,7 @@ __global__ __launch_bounds__(GS_PIX) void grid_score_kernel(const float* __restr
         if (clu) cl = clu[(size_t)min(b0 + j, B - 1) * HW + pc];
 #pragma unroll
         for (int i = 0; i < GS_TN; ++i) {
-            float v = clu ? fmaxf(acc[i][j], cl) : acc[i][j];
+            float v = clu ? max_nan(acc[i][j], cl) : acc[i][j];
             v = valid ? v : 0.0f;
             v = wave_sum(v);
             if (lane == 0) red[wave][i * GS_TB + j] = v;
@@ -946,7 +946,7 @@ __global__ void vertex_similarity_kernel(const float* __restrict__ table, const 
         const float* t = table + (size_t)b * table_image_elems(V, HW);
         float best = -__builtin_inff();
         for (int v = 0; v < V; ++v) best = fmaxf(best, t[table_offset((V + 3) >> 2, v, p)]);
-        s += fmaxf(best, clu[(size_t)b * HW + p]);
+        s += max_nan(best, clu[(size_t)b * HW + p]);
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -1205,10 +1205,10 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     sk[k] = pixel_score(s.verts[vi[k][0]], s.verts[vi[k][1]], s.verts[vi[k][2]], s.xs[qx[k]], s.ys[qy[k]], dd[k]);
                 }
                 const float obj = (wq[0] * sk[0] + wq[1] * sk[1]) + (wq[2] * sk[2] + wq[3] * sk[3]);
-                const float dlt = fmaxf(obj, cl) - fmaxf(0.0f, cl);
+                const float dlt = max_nan(obj, cl) - fmaxf(0.0f, cl);
                 dmax += dlt;
                 if (last && yt >= br0 && yt < br1 && xt >= bc0 && xt < bc1) dbox += dlt;
-                const float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : 0.0f);
+                const float mk = obj > cl ? 1.0f : (obj == cl ? 0.5f : (__builtin_isunordered(obj, cl) ? obj + cl : 0.0f));
                 if (mk == 0.0f) continue;
                 const float g = -mk * a.inv_norm;
 #pragma unroll
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     const float4 v0 = s.verts[vi[u][0]], v1 = s.verts[vi[u][1]], v2 = s.verts[vi[u][2]];
                     const float obj = pixel_fused(cam_a, vinv.ia, vinv.bx, vinv.by, v0, v1, v2, s.xs[px[u]], s.ys[py[u]], dd[u],
                                                   cc_[u], wg[u] * a.inv_norm, &acc);
-                    const float dlt = (fmaxf(obj, cc_[u]) - fmaxf(0.0f, cc_[u])) * wg[u];
+                    const float dlt = (max_nan(obj, cc_[u]) - fmaxf(0.0f, cc_[u])) * wg[u];
                     dmax += dlt;
                     if (last && py[u] >= br0 && py[u] < br1 && px[u] >= bc0 && px[u] < bc1) dbox += dlt;
                 }

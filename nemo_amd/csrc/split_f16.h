@@ -20,7 +20,14 @@ constexpr int SG_NP = 2;                        // f16 pieces per f32 value
 constexpr float SG_FEAT_SCALE = 256.0f;         // feature maps are unit vectors per pixel: scaled values stay far inside f16
 constexpr float SG_FEAT_LIMIT = 65504.0f;       // largest finite f16: scaled values beyond it are clamped
 
-__device__ inline float scale_clamp(float x) { return fminf(fmaxf(x * SG_FEAT_SCALE, -SG_FEAT_LIMIT), SG_FEAT_LIMIT); }
+// A NaN stays a NaN (fminf / fmaxf alone would turn it into the limit), as in the f32 paths.
+__device__ inline float scale_clamp(float x) {
+    const float y = x * SG_FEAT_SCALE;
+    return y != y ? y : fminf(fmaxf(y, -SG_FEAT_LIMIT), SG_FEAT_LIMIT);
+}
+
+// torch.max(a, b) semantics: NaN if either operand is NaN (fmaxf alone returns the other operand).
+__device__ inline float max_nan(float a, float b) { return __builtin_isunordered(a, b) ? a + b : fmaxf(a, b); }
 
 __device__ inline void split2(float x0, float x1, uint32_t* h, uint32_t* l) {
     const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;

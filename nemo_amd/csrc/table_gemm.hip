@@ -328,7 +328,7 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const BankMeta*
             if (kg < NKG) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    x[it][j] = pok ? fminf(fmaxf(x[it][j] * SG_FEAT_SCALE, -SG_FEAT_LIMIT), SG_FEAT_LIMIT) : 0.0f;
+                    x[it][j] = pok ? scale_clamp(x[it][j]) : 0.0f;
                 uint4 pcs[SG_NP];
                 split8(x[it], pcs);
 #pragma unroll

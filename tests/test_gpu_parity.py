@@ -905,7 +905,9 @@ def test_keypoint_corr_matches_oracle(small):
 
 @pytest.mark.parametrize("optimize_translation", [True, False])
 def test_flow_solve_first_steps_track_oracle(small, optimize_translation):
-    """nemo_solve_flow against autograd through render + flow_warp + Adam (constant learning rate)."""
+    """nemo_solve_flow against autograd through render + flow_warp + Adam (constant learning rate): the loss of
+    every one of the first 20 steps (1e-4 for the first six, 1e-3 up to step 20) and the parameters after 6 and
+    after 20 updates."""
     from nemo_amd import ops
     sc = small
     fm, gts = sc.feature_maps(1, first_seed=40)
@@ -913,19 +915,33 @@ def test_flow_solve_first_steps_track_oracle(small, optimize_translation):
     C0, th0 = random_poses(3, seed=9, dist=(4.8, 5.2))
     fl0 = torch.tensor([[0.13, -0.21], [-0.34, 0.08], [0.017, -0.023]])       # off the pixel grid: see the kernel's note on kinks
     tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
-    pose, lh = ops.solve_flow(sc.mod.mesh, sc.mod.camera(), tab, clu.to(sc.device), C0.to(sc.device), th0.to(sc.device),
-                              fl0.to(sc.device), hyp_to_image=torch.zeros(3, dtype=torch.int32), global_batch=1,
-                              optimize_translation=optimize_translation, translation_scale=0.1, steps=6, history=True)
-    pose, lh = pose.cpu(), lh.cpu()
+
+    def run(steps):
+        pose, lh = ops.solve_flow(sc.mod.mesh, sc.mod.camera(), tab, clu.to(sc.device), C0.to(sc.device), th0.to(sc.device),
+                                  fl0.to(sc.device), hyp_to_image=torch.zeros(3, dtype=torch.int32), global_batch=1,
+                                  optimize_translation=optimize_translation, translation_scale=0.1, steps=steps, history=True)
+        return pose.cpu(), lh.cpu()
+
+    pose6, lh6 = run(6)
+    pose20, lh20 = run(20)
+    assert torch.equal(lh20[:, :6], lh6)
     for i in range(3):
         Cr, thr, flr, score, hist = R.refine_proposal(sc.ref, fm, clu, C0[i], th0[i], fl0[i], optimize_translation, 0.1,
                                                       epochs=6, record=True)
-        assert rel_err(lh[i], torch.tensor(hist)) < REL, (i, lh[i], hist)
-        assert rel_err(pose[i, 0:3], Cr) < 2e-4 and abs(float(pose[i, 3] - thr)) < 1e-3
-        assert float((pose[i, 4:6] - flr).abs().max()) < 1e-3
-        assert abs(float(pose[i, 6]) - score) < 1e-4
+        assert rel_err(lh6[i], torch.tensor(hist)) < REL, (i, lh6[i], hist)
+        assert rel_err(pose6[i, 0:3], Cr) < 2e-4 and abs(float(pose6[i, 3] - thr)) < 1e-3
+        assert float((pose6[i, 4:6] - flr).abs().max()) < 1e-3
+        assert abs(float(pose6[i, 6]) - score) < 1e-4
         if not optimize_translation:
-            assert torch.equal(pose[i, 4:6], fl0[i])
+            assert torch.equal(pose6[i, 4:6], fl0[i])
+        Cr, thr, flr, score, hist = R.refine_proposal(sc.ref, fm, clu, C0[i], th0[i], fl0[i], optimize_translation, 0.1,
+                                                      epochs=20, record=True)
+        assert rel_err(lh20[i], torch.tensor(hist)) < 1e-3, (i, lh20[i], hist)
+        # (random far-off starts: Adam's normalised step turns rounding-level differences of a small gradient
+        # component into milliradians of theta within 20 steps)
+        assert rel_err(pose20[i, 0:3], Cr) < 3e-3 and abs(float(pose20[i, 3] - thr)) < 1e-2, (i, pose20[i], Cr, thr)
+        assert float((pose20[i, 4:6] - flr).abs().max()) < 1e-2
+        assert abs(float(pose20[i, 6]) - score) < 1e-3
 
 
 def test_keypoint_solve_pose_drop_in(small):
@@ -933,9 +949,8 @@ def test_keypoint_solve_pose_drop_in(small):
     The reference never steps the learning-rate scheduler on this path (solve_pose.py:252-280), so Adam keeps
     hopping around the optimum with a constant 0.05 step: the pose after N steps is reproducible to about a
     degree only (the oracle itself lands 0.25 degree apart on two x86 hosts).  Proposals must match exactly;
-    the refined angles are compared at 3 degrees (Adam's hop of theta is 0.05 rad = 2.9 degrees), and both must
-    sit within 3 degrees of the ground truth; the first steps of the same loop are held to 1e-4 by
-    test_flow_solve_first_steps_track_oracle."""
+    the refined angles are compared at 1.5 degrees and both must sit within 3 degrees of the ground truth; the
+    first 20 steps of the same loop are held to 1e-4 / 1e-3 by test_flow_solve_first_steps_track_oracle."""
     from nemo_amd.solve_pose_keypoint import solve_pose
     from nemo_amd.utils import ConfigNode
     sc = small
@@ -961,12 +976,12 @@ def test_keypoint_solve_pose_drop_in(small):
         assert float(pred["pre_rendering_poses"][0][k]) == float(extrema_ref[0][k]), k
     got, ref = pred["final"][0], final_ref[0]
     for k in ("azimuth", "elevation", "theta"):
-        assert angle_diff_deg(got[k], ref[k]) < 3.0, (k, got, ref)
+        assert angle_diff_deg(got[k], ref[k]) < 1.5, (k, got, ref)
         assert angle_diff_deg(got[k], gts[0][k]) < 3.0 and angle_diff_deg(ref[k], gts[0][k]) < 3.0, (k, got, ref, gts[0])
     assert abs(got["distance"] - ref["distance"]) < 0.05
     # one Adam hop of the flow is lr / translation_scale = 0.5 feature pixel = 4 image pixels
-    assert abs(got["principal"][0] - ref["principal"][0]) < 8.0 and abs(got["principal"][1] - ref["principal"][1]) < 8.0
-    assert abs(got["score"] - ref["score"]) < 2e-2          # the loss of the last hop, see the docstring
+    assert abs(got["principal"][0] - ref["principal"][0]) < 4.0 and abs(got["principal"][1] - ref["principal"][1]) < 4.0
+    assert abs(got["score"] - ref["score"]) < 1e-2          # the loss of the last hop, see the docstring
     assert pred["object_idx_map"].shape == (sc.H, sc.W) and pred["seg_maps"].shape == (1, sc.H, sc.W)
     assert {"pre_compute_time", "pre_rendering_time", "optimization_time"} <= set(pred)
 
@@ -1245,3 +1260,33 @@ def test_grid_score_recentred_equals_align_then_score(small, padding_mode):
     loss3, amin3, _ = ops.grid_score_recentred(packed, fmd, None, d_src, d_tgt, p_src, p_tgt, padding_mode=padding_mode)
     loss4, amin4, _ = ops.grid_score(None, copies, None, packed=packed)
     assert torch.equal(loss3, loss4) and torch.equal(amin3, amin4)
+
+
+def test_nan_features_stay_nan_on_the_matrix_cores(small):
+    """A NaN in the backbone output must not turn into a finite score: the matrix-core table and grid scoring
+    propagate it like the f32 forms do (the f16 split clamps magnitudes, it must not clamp a NaN)."""
+    import nemo_amd
+    from nemo_amd import ops
+    sc = small
+    fm, _ = sc.feature_maps(2, first_seed=90)
+    fm[1, 3, sc.H // 2, sc.W // 2] = float("nan")           # a pixel the object covers
+    fmd = fm.to(sc.device)
+    table = ops.similarity_table(sc.mod.mesh, fmd)
+    tab = ops.table_dense(table, sc.mod.mesh.V, sc.H * sc.W)
+    p = (sc.H // 2) * sc.W + sc.W // 2
+    assert torch.isnan(tab[1, :, p]).all() and torch.isfinite(tab[0]).all()
+    assert torch.isfinite(tab[1, :, :p]).all() and torch.isfinite(tab[1, :, p + 1:]).all()
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    loss, _, _ = ops.grid_score(None, fmd, None, packed=maps._nemo_packed_grid)
+    loss_v, _, _ = ops.grid_score(maps.squeeze(1), fmd, None)
+    assert torch.isfinite(loss[0]).all() and torch.isnan(loss[1]).all() and torch.isnan(loss_v[1]).all()
+    clu = ops.clutter_score(fmd, sc.clutter.to(sc.device))
+    assert torch.isnan(clu[1, sc.H // 2, sc.W // 2]) and torch.isfinite(clu[0]).all()
+    loss_c, _, _ = ops.grid_score(None, fmd, clu, packed=maps._nemo_packed_grid)
+    loss_cv, _, _ = ops.grid_score(maps.squeeze(1), fmd, clu)
+    assert torch.isfinite(loss_c[0]).all() and torch.isnan(loss_c[1]).all() and torch.isnan(loss_cv[1]).all()
+    # and in the optimisation loop: the reference's loss, gradients and therefore poses are NaN for that image
+    C0, th0 = random_poses(2, seed=2, dist=(5.0, 5.0))
+    pose, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), table, clu, C0.to(sc.device), th0.to(sc.device), steps=3)
+    assert torch.isfinite(pose[0]).all() and torch.isnan(pose[1, :4]).all() and torch.isnan(pose[1, 6:]).all()
