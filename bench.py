@@ -105,9 +105,9 @@ def main():
     ap.add_argument("--hypotheses", type=int, default=1,
                     help="initial poses per image (the K best grid poses; BASELINE configs[2] uses 8); 1 = configs[1]")
     ap.add_argument("--streams", type=int, default=2, help="launch streams the groups alternate over")
-    ap.add_argument("--partial-table", type=int, default=0, metavar="ROWS",
-                    help="compute only the table tiles each 32-vertex block is expected to meet (rows of the block at the grid pose "
-                         "+- ROWS) and repeat the hypotheses that leave them on a complete table; 0 = the complete table")
+    ap.add_argument("--complete-table", action="store_true",
+                    help="compute the complete vertex x pixel similarity table in front of the solve (nemo_similarity_table + "
+                         "nemo_solve) instead of letting the solve compute the tiles it needs (nemo_solve_features, the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true",
                     help="let the groups on different launch streams start together (default: a group's clutter / grid / table "
@@ -158,7 +158,9 @@ def main():
     hyp_image = torch.arange(G * B, device=dev, dtype=torch.int32).repeat_interleave(K_HYP)
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    tables = [torch.empty(ops.table_shape(mod.mesh, G * B, H * W), device=dev) for _ in range(n_streams)]
+    # per launch stream: room for the similarity tables (complete, or the tiles the solve computes for itself) + feature fragments
+    work = [torch.empty(ops.solve_workspace_bytes(mod.mesh, G * B, H * W), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
+    tables = [ops.workspace_tables(mod.mesh, w_, G * B, H * W) for w_ in work]
     gathered = [[torch.empty(G * B, 7, device=dev) for _ in range(world)] for _ in range(n_streams)] if world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}
@@ -166,7 +168,6 @@ def main():
     # Staggered groups: the front kernels (clutter, grid, table: HBM / matrix-core bound) of group k+1 wait for the
     # front kernels of group k, so they run beside solve(k) (vector-issue / latency bound) instead of beside front(k).
     front_ev = [None]
-    n_repeated = [None]
     stagger = not args.no_stagger and n_streams > 1
 
     def one_group(g, timed=False, host_out=None, slot=0):
@@ -190,12 +191,7 @@ def main():
         idx = idx.long()
         if timed:
             ev[2].record()
-        partial = args.partial_table > 0 and K_HYP == 1
-        if partial:
-            ranges = ops.table_ranges(mod.mesh, cam, cs[idx], ths[idx], None, args.partial_table)
-            flags = torch.zeros(n, dtype=torch.int32, device=dev)
-            tab = ops.similarity_table_partial(mod.mesh, x, table[:n], ranges=ranges)
-        else:
+        if args.complete_table:
             tab = ops.similarity_table(mod.mesh, x, out=table[:n])
         if stagger:
             front_ev[0] = torch.cuda.Event()
@@ -203,13 +199,10 @@ def main():
         if timed:
             ev[3].record()
         skw = dict(global_batch=B * world, dof=3, steps=EPOCHS, lr=0.05, betas=(0.4, 0.6), lr_gamma=0.2, lr_every=EPOCHS // 3)
-        if partial:     # hypotheses that leave their ranges are repeated on their complete table (device-side flags, no sync)
-            pose = ops.solve_partial(mod.mesh, cam, tab, clu, cs[idx], ths[idx], ranges=ranges, miss_flags=flags, **skw)
-            ops.similarity_table_partial(mod.mesh, x, table[:n], only_flagged=flags)
-            ops.solve_partial(mod.mesh, cam, tab, clu, cs[idx], ths[idx], only_flagged=flags, out=pose, **skw)
-            n_repeated[0] = flags
-        else:
+        if args.complete_table:
             pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], hyp_to_image=h2i, **skw)
+        else:           # the table tiles are computed inside the solve, when a covered pixel first needs one
+            pose, _ = ops.solve_from_features(mod.mesh, cam, x, clu, cs[idx], ths[idx], hyp_to_image=h2i, workspace=work[slot], **skw)
         if timed:
             ev[4].record()
         if K_HYP > 1:       # keep the best-scoring hypothesis of every image
@@ -310,8 +303,8 @@ def main():
                                    "80x100x128 feature maps, cuboid mesh V=1118 F=1904, 144-pose pre-rendered grid scoring + "
                                    "300 Adam steps per image, random-init vertex bank",
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": int(pre.shape[0]), "adam_steps": EPOCHS,
-                       "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger, "partial_table_margin_rows": args.partial_table,
-                       "repeated_in_last_group": None if n_repeated[0] is None else int(n_repeated[0].sum()), "hypotheses_per_image": K_HYP,
+                       "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger, "similarity_table": "complete, in front of the solve" if args.complete_table else "tiles on demand inside the solve",
+                       "hypotheses_per_image": K_HYP,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B * K_HYP,
             "median_pose_error_deg_vs_synthetic_gt": med_err,

@@ -267,29 +267,25 @@ int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table
                     int32_t optimize_translation, float translation_scale, const nemo_adam* opt,
                     float* out_pose, float* out_loss_hist, void* stream);
 
-/* ---- partial similarity tables (no counterpart in the reference, which scores every pixel against the
- * rendered map; an optimisation of nemo_similarity_table + nemo_solve for one hypothesis per image) ----
- * The optimisation loop of batch_solve_pose.py:306-338 reads table entry (vertex, pixel) only where a face of
- * that vertex covers the pixel.  nemo_table_ranges projects every 32-vertex block at the starting pose and
- * returns, per image and block, the first and last 128-pixel tile of the rows the block falls in, widened by
- * margin_rows: out_ranges [n][nemo_table_range_blocks(mesh)][2] int32.  nemo_similarity_table_partial computes
- * only those (tile, block) products (the rest of `table` is left as it was); with only_flagged [B] it instead
- * computes the complete table of the images whose entry is non-zero.  nemo_solve_partial is nemo_solve for
- * n_hyp == n_img with such a table: a hypothesis whose faces need a tile outside its ranges sets
- * miss_flags[h] = 1 (the caller zeroes the array; the hypothesis's output row is then void); with only_flagged
- * [n_img] only the hypotheses with a non-zero entry run.  A caller repeats flagged images as
- *   nemo_similarity_table_partial(..., NULL, miss_flags, table); nemo_solve_partial(..., NULL, NULL, miss_flags, ...)
- * after which every row equals what nemo_similarity_table + nemo_solve give, bit for bit. */
-int32_t nemo_table_range_blocks(nemo_mesh_t mesh);
-int nemo_table_ranges(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
-                      const float* principal, int32_t n, int32_t margin_rows, int32_t* out_ranges, void* stream);
-int nemo_similarity_table_partial(nemo_mesh_t mesh, const float* feat, int32_t B, int32_t HW, const int32_t* table_ranges,
-                                  const int32_t* only_flagged, float* table, void* stream);
-int nemo_solve_partial(nemo_mesh_t mesh, const nemo_camera* cam, const float* table, const float* clutter_score,
-                       const float* init_campos, const float* init_theta, const float* init_principal,
-                       const int32_t* score_boxes, int32_t n_img, int32_t global_batch, int32_t dof,
-                       const nemo_adam* opt, const int32_t* table_ranges, int32_t* miss_flags,
-                       const int32_t* only_flagged, float* out_pose, float* out_loss_hist, void* stream);
+/* ---- the optimisation loop straight from the feature maps ------------------------------------------------------
+ * nemo_solve / nemo_solve_parts without a precomputed table (no counterpart in the reference, which recomputes the
+ * whole rendered map and its product with the image at every step, batch_solve_pose.py:320-338).  The loop reads
+ * table entry (vertex, pixel) only where a face of that vertex covers the pixel during some step - about one entry
+ * in a hundred - so the kernel computes the table itself, one tile of 32 vertices x 32 pixels at a time, the first
+ * time a covered pixel needs it, with the same matrix-core product as nemo_similarity_table (every entry it reads
+ * is bit for bit what nemo_similarity_table would have written; results equal nemo_similarity_table + nemo_solve
+ * bit for bit).  feat [n_img,C,HW] are the images' feature maps; workspace is device memory of
+ * nemo_solve_features_workspace(mesh, n_img, HW) bytes that need not be initialised: room for the tables in the
+ * layout of nemo_similarity_table (n_img * nemo_similarity_table_elems floats; only the computed tiles are written,
+ * the rest stays undefined).  hyp_to_part may be NULL (whole handle).  Several hypotheses may refine against one
+ * image.  C must be 16, 32, 64 or 128 (the workspace size is 0 and the call returns NEMO_ERR_UNSUPPORTED otherwise:
+ * use nemo_similarity_table + nemo_solve). */
+size_t nemo_solve_features_workspace(nemo_mesh_t mesh, int32_t n_img, int32_t HW);
+int nemo_solve_features(nemo_mesh_t mesh, const nemo_camera* cam, const float* feat, void* workspace, size_t workspace_bytes,
+                        const float* clutter_score, const int32_t* hyp_to_image, const int32_t* hyp_to_part,
+                        const float* init_campos, const float* init_theta, const float* init_principal,
+                        const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
+                        const nemo_adam* opt, float* out_pose, float* out_loss_hist, void* stream);
 
 /* camera_position_to_spherical_angle (nemo/utils/mesh.py:50-56) on device:
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */

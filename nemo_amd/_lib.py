@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnemo_hip.so")
+LIB_PATH = os.environ.get("NEMO_HIP_LIB") or os.path.join(_HERE, "libnemo_hip.so")      # NEMO_HIP_LIB: a diagnostic build
 
 # every symbol include/nemo_hip.h declares
 SYMBOLS = [
@@ -20,7 +20,7 @@ SYMBOLS = [
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
     "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
-    "nemo_table_range_blocks", "nemo_table_ranges", "nemo_similarity_table_partial", "nemo_solve_partial",
+    "nemo_solve_features_workspace", "nemo_solve_features",
     "nemo_project_keypoints", "nemo_gather_features", "nemo_gather_features_backward", "nemo_gather_idx", "nemo_mask_weight",
 ]
 
@@ -87,11 +87,10 @@ def load():
     lib.nemo_align_maps.argtypes = [f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, vp]
     lib.nemo_spherical_angles.argtypes = [f32p, i32, f32p, vp]
     lib.nemo_project_keypoints.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, f32p, i32, C.c_float, i32, f32p, vp, vp]
-    lib.nemo_table_range_blocks.argtypes = [vp]
-    lib.nemo_table_ranges.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, i32, vp, vp]
-    lib.nemo_similarity_table_partial.argtypes = [vp, f32p, i32, i32, vp, vp, f32p, vp]
-    lib.nemo_solve_partial.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, f32p, f32p, vp, i32, i32, i32,
-                                       C.POINTER(NemoAdam), vp, vp, vp, f32p, f32p, vp]
+    lib.nemo_solve_features_workspace.argtypes = [vp, i32, i32]
+    lib.nemo_solve_features_workspace.restype = C.c_size_t
+    lib.nemo_solve_features.argtypes = [vp, C.POINTER(NemoCamera), f32p, vp, C.c_size_t, f32p, vp, vp, f32p, f32p, f32p, vp, i32, i32,
+                                        i32, i32, C.POINTER(NemoAdam), f32p, f32p, vp]
     lib.nemo_gather_features.argtypes = [f32p, f32p, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32p, f32p, vp, vp]
     lib.nemo_gather_features_backward.argtypes = [f32p, f32p, f32p, f32p, vp, i32, i32, i32, f32p, f32p, vp]
     lib.nemo_gather_idx.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
@@ -99,7 +98,8 @@ def load():
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("nemo_last_error", "nemo_version", "nemo_grid_score_workspace", "nemo_similarity_table_elems",
-                        "nemo_grid_pack_bytes", "nemo_grid_score_packed_workspace", "nemo_grid_score_recentred_workspace"):
+                        "nemo_grid_pack_bytes", "nemo_grid_score_packed_workspace", "nemo_grid_score_recentred_workspace",
+                        "nemo_solve_features_workspace"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -1,12 +1,13 @@
 """Batched render-and-compare pose solver on HIP.
 
 Drop-in for reference nemo/models/batch_solve_pose.py: get_pre_render_samples (:43-62) and
-solve_pose (:194-372) keep their signatures and return values.  The work is done by four launches:
+solve_pose (:194-372) keep their signatures and return values.  The work is done by three launches:
 
   1. nemo_clutter_score      feature map x clutter vectors                      (:214-225)
   2. nemo_grid_score         all images x all pre-rendered poses, arg-min       (:128-164)
-  3. nemo_similarity_table   vertex x pixel similarity on the matrix cores      (one GEMM per image)
-  4. nemo_solve              cfg.inference.epochs Adam steps inside one launch  (:306-338)
+  3. nemo_solve_features     cfg.inference.epochs Adam steps inside one launch  (:306-338); the vertex x pixel
+                             similarity tiles the steps read are computed on the matrix cores inside the same launch
+                             (channel counts other than 16/32/64/128: nemo_similarity_table + nemo_solve)
 
 followed by one device->host copy of the [B, 8] result.  PyTorch only allocates tensors here.
 """
@@ -267,10 +268,14 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     opt_dof = 6 if (dof == 6 or cfg.get("optimize_translation", False)) else dof
     cam = inter_module.camera()
     boxes = None if bbox is None else score_boxes_from_bbox(bbox, b, n_hyp, kwargs.get("down_sample_rate", 8))
-    table = ops.similarity_table(inter_module.mesh, feature_map)
-    pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, init_principal, h2i,
-                        global_batch=kwargs.get("global_batch", b), dof=opt_dof, steps=epochs,
-                        lr_every=epochs // 3 if epochs >= 3 else 0, score_boxes=boxes, **adam)
+    skw = dict(global_batch=kwargs.get("global_batch", b), dof=opt_dof, steps=epochs, lr_every=epochs // 3 if epochs >= 3 else 0,
+               score_boxes=boxes, **adam)
+    if ops.on_demand_table_supported(inter_module.mesh):
+        # the vertex x pixel similarity tiles are computed inside the solve, when a covered pixel first needs one
+        pose, _ = ops.solve_from_features(inter_module.mesh, cam, feature_map, clutter_score, init_C, init_theta, init_principal, h2i, **skw)
+    else:
+        table = ops.similarity_table(inter_module.mesh, feature_map)
+        pose, _ = ops.solve(inter_module.mesh, cam, table, clutter_score, init_C, init_theta, init_principal, h2i, **skw)
     sph = ops.spherical_angles(pose[:, 0:3])
     host = torch.cat([pose, sph], dim=1).cpu().numpy()     # the one device->host copy
     t3 = time.time()

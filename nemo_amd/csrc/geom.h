@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "split_f16.h"      // max_nan
+
 #pragma clang fp contract(off)
 
 namespace nemo {
@@ -56,9 +58,6 @@ struct PoseCam {
     int cull;                    // optimisation loop: faces looking away from the camera may be skipped this step
     float qz0, qc;               // optimisation loop: start of the quantised depth range, and 2^23 - start in steps
 };
-
-// torch.max(a, b) semantics: NaN if either operand is NaN (fmaxf alone returns the other operand).
-__device__ inline float max_nan(float a, float b) { return __builtin_isunordered(a, b) ? a + b : fmaxf(a, b); }
 
 __device__ inline void normalize3(float x, float y, float z, float* o, float* n_out) {
     float n = sqrtf((x * x + y * y) + z * z);

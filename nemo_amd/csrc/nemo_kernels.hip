@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <new>
 #include <map>
 #include <mutex>
@@ -51,6 +52,8 @@ static int fail(int code, const char* fmt, ...) {
             return fail(NEMO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                                  \
     } while (0)
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" const char* nemo_last_error(void) { return g_err; }
 extern "C" const char* nemo_version(void) { return "nemo_hip 0.1 (gfx950, f32)"; }
@@ -180,8 +183,7 @@ void launch_split_bank(const float* memory, void* frag, int V, int C, hipStream_
 int launch_grid_mfma_recentred(const void* packed, const float* feat_src, const float* clu, int N, int B, int C, int Bsrc, int h1, int w1,
                                int h0, int w0, int border, const float* dist_src, const float* dist_tgt, const float* p_src,
                                const float* p_tgt, void* featp, float* partial, hipStream_t st);
-int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, const int32_t* ranges,
-                       const int32_t* only, hipStream_t st);
+int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
 int split_bank_blocks(int V);
 }
 
@@ -354,13 +356,13 @@ static int plan_layout(int H, int W, int V, int F, int threads, LdsLayout* L) {
 }
 
 // Layout and key format of the optimisation loop (make_solve_layout, depth_key32).
-static int plan_solve(int H, int W, int V, int F, int threads, const float* aabb, RasterCtx* rc) {
+static int plan_solve(int H, int W, int V, int F, int threads, const float* aabb, RasterCtx* rc, int vblocks = 0) {
     if (H > kMaxSide || W > kMaxSide || F >= kMaxFaces)
         return fail(NEMO_ERR_UNSUPPORTED, "map %dx%d / %d faces exceed the rasteriser's limits (%d x %d pixels, %d faces)", H, W, F,
                     kMaxSide, kMaxSide, kMaxFaces - 1);
     const bool packable = V <= kPackedFaceVerts;
-    rc->L = make_solve_layout(H, W, V, F, packable, threads / 64);
-    if (!packable || rc->L.total > kMaxLds) rc->L = make_solve_layout(H, W, V, F, false, threads / 64);
+    rc->L = make_solve_layout(H, W, V, F, packable, threads / 64, vblocks);
+    if (!packable || rc->L.total > kMaxLds) rc->L = make_solve_layout(H, W, V, F, false, threads / 64, vblocks);
     if (rc->L.total > kMaxLds)
         return fail(NEMO_ERR_UNSUPPORTED,
                     "map %dx%d with %d vertices needs %d bytes of LDS per workgroup (limit %d)", H, W, V,
@@ -858,7 +860,6 @@ extern "C" int nemo_grid_pack(const float* pre, int32_t N, int32_t C, int32_t HW
     return NEMO_OK;
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t nemo_grid_score_packed_workspace(int32_t N, int32_t B, int32_t C, int32_t HW) {
     if (N <= 0 || B <= 0 || C <= 0 || HW <= 0 || !nemo::grid_mfma_supported(C)) return 0;
@@ -976,16 +977,17 @@ struct OptState {
     float P[6];                 // parameter values (mirror of the registers of wave 0)
     float first_loss, last_loss;
     float base_max, base_clu, box_max, box_clu, box_n;   // per-image constants of the loss (see solve_kernel)
+    float out_lo[3], out_hi[3];  // the mesh's bounding box with a margin: a camera beyond it is outside the solid
 };
 
 struct SolveArgs {
     RasterCtx rc;
-    const float* table; const float* clu; const int32_t* hyp_to_image;
+    float* table; const float* clu; const int32_t* hyp_to_image;
     const float* init_campos; const float* init_theta; const float* init_principal;
     const int32_t* score_boxes;
-    const int32_t* ranges; int nvb;      // partial similarity table: [n_img][nvb][2] first / last pixel tile per 32-vertex block, or null
-    int32_t* miss;                       // [n_hyp]: set to 1 when the hypothesis needed a tile outside the ranges (its result is then void)
-    const int32_t* only;                 // [n_hyp] or null: hypotheses with a zero entry are left alone
+    // table tiles computed on demand (ONDEMAND): the images' feature maps [n_img, C, HW] and the vertex bank as matrix-core
+    // fragments (the two operands of the table product) and what it takes to address them; `table` is then written by the kernel
+    const float* feat; const uint4* bank; size_t apiece; const BankMeta* meta; int nks, nfb;
     const MeshPart* parts; const int32_t* hyp_to_part; int n_parts;   // a handle of several meshes: hypothesis h rasterises part hyp_to_part[h]
     int table_vg;                        // vertex groups of 4 per pixel tile of the table (all vertices of the handle)
     float def_px, def_py;
@@ -1001,14 +1003,13 @@ struct SolveArgs {
 // (flow_warp.py: grid_sample, align_corners=True, border padding) before it is compared with the image.
 // Two workgroups per compute unit (four waves per SIMD, 128 registers): while one hypothesis is in a serial
 // section (pose set-up, the gradient chain, Adam) or waits on LDS, the other one's waves issue.
-template <bool FL, bool WARP, bool PARTIAL = false>
+template <bool FL, bool WARP, bool ONDEMAND = false>
 __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
     const int h = blockIdx.x, tid = threadIdx.x;
     const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W;
     const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
-    if (a.only && a.only[h] == 0) return;
     // The mesh this hypothesis renders: the whole handle, or one of its parts (uniform over the workgroup).
     RasterCtx rc = a.rc;
     int part = 0;
@@ -1018,9 +1019,12 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             const MeshPart q = a.parts[part];
             rc.verts = a.rc.verts + 3 * (size_t)q.v0; rc.faces = a.rc.faces + 3 * (size_t)q.f0; rc.vbase = q.v0;
             rc.V = q.nv; rc.F = q.nf;
+            // (uniform values, pinned to scalar registers: they live over the whole step loop)
+            auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
 #pragma unroll
-            for (int k = 0; k < 6; ++k) rc.aabb[k] = q.aabb[k];
-            rc.face_bits = q.face_bits; rc.depth_margin = q.depth_margin; rc.depth_scale = q.depth_scale; rc.depth_qmax = q.depth_qmax;
+            for (int k = 0; k < 6; ++k) rc.aabb[k] = uni(q.aabb[k]);
+            rc.face_bits = __builtin_amdgcn_readfirstlane(q.face_bits);
+            rc.depth_margin = uni(q.depth_margin); rc.depth_scale = uni(q.depth_scale); rc.depth_qmax = uni(q.depth_qmax);
         }
     }
     const int V = rc.V, vbase = rc.vbase;
@@ -1034,14 +1038,14 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     const float* tab = a.table + (size_t)img * ((size_t)((HW + kTabTile - 1) >> kTabShift) * vg_n * kTabTile * 4);
     const float* clu = a.clu + (size_t)img * HW;
     solve_prologue(rc, s);
-    if (PARTIAL) {
-        for (int k = tid; k < a.nvb; k += blockDim.x) {
-            const int32_t* r = a.ranges + ((size_t)img * a.nvb + k) * 2;
-            s.need[k] = (unsigned)min(max(r[0], 0), 0xFFFF) | (unsigned)min(max(r[1], 0), 0xFFFF) << 16;
-        }
-        s.miss = a.miss + h;
-    } else {
-        s.need = nullptr;
+    TileCtx tc = {};
+    if (ONDEMAND) {
+        tc.feat = a.feat + (size_t)img * (a.nks * 16) * HW; tc.HW = HW;
+        tc.table = a.table + (size_t)img * ((size_t)((HW + kTabTile - 1) >> kTabShift) * vg_n * kTabTile * 4);
+        tc.bank = a.bank; tc.apiece = a.apiece; tc.unscale = a.meta->unscale; tc.nks = a.nks;
+        tc.vg_n = vg_n; tc.vb_first = vbase >> 5; tc.nvb = ((vbase + V - 1) >> 5) - tc.vb_first + 1;
+        tc.nfb = a.nfb;
+        build_face_block_masks<FL>(rc, s, tc);
     }
 
     // Adam's per-step constants (torch single-tensor path: bias corrections and step size in double, then
@@ -1064,6 +1068,11 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         os->P[4] = a.init_principal ? a.init_principal[2 * h] : (WARP ? 0.0f : a.def_px);
         os->P[5] = a.init_principal ? a.init_principal[2 * h + 1] : (WARP ? 0.0f : a.def_py);
         os->first_loss = 0.0f; os->last_loss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float m = 1e-3f * (rc.aabb[3 + k] - rc.aabb[k]) + 1e-6f;
+            os->out_lo[k] = rc.aabb[k] - m; os->out_hi[k] = rc.aabb[3 + k] + m;
+        }
     }
     // per-image constants of the loss: sum_p max(0, clu) (what an uncovered image scores) and sum_p clu
     // They are parked in the optimiser state (dedicated LDS words written once by thread 0): s.tot is
@@ -1127,10 +1136,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                 // back faces may be skipped while the camera is outside the solid (outside its bounding box, with a margin)
                 bool outside = false;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float m = 1e-3f * (rc.aabb[3 + k] - rc.aabb[k]) + 1e-6f;
-                    outside = outside || P[k] < rc.aabb[k] - m || P[k] > rc.aabb[3 + k] + m;
-                }
+                for (int k = 0; k < 3; ++k) outside = outside | (P[k] < os->out_lo[k]) | (P[k] > os->out_hi[k]);
                 s.pc->cull = rc.outward && outside;
                 // depth range of the keys: the vertices lie within the bounding radius of the mesh origin, whose view depth is T_z
                 const float z0 = s.pc->T[2] - rc.depth_margin;
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         STAMP(0);
         if (verts_resident) project_vertices_resident(rc, s, wv); else project_vertices(rc, s);
         STAMP(1);
-        raster_direct<FL, PARTIAL>(rc, s);
+        raster_direct<FL>(rc, s);
 #ifdef NEMO_STAMPS_P1
         if (tid == 0 && a.out_hist) for (int k = 0; k < 6; ++k) a.out_hist[(size_t)h * a.steps + 16 + k] += s.tot[k] / (float)a.steps;
 #endif
@@ -1227,6 +1233,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         } else {
         int first_chunk;
         const int cnt = compact_covered32(rc, s, row0, row1, &first_chunk);
+        if (ONDEMAND) ensure_table_tiles(rc, s, tc, first_chunk, cnt);
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
 #endif
@@ -1345,35 +1352,54 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
-static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
+// `feat` non-null: the similarity table is computed on demand by the kernel (`table` = workspace that need not be
+// initialised); feat null: `table` is the complete table of nemo_similarity_table.
+static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, float* table, const float* clu,
                       const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
                       const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
                       int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
-                      const int32_t* table_ranges, int32_t* miss_flags, const int32_t* only, const int32_t* hyp_to_part,
-                      void* stream) {
+                      const int32_t* hyp_to_part, void* stream) {
     if (n_hyp == 0) return NEMO_OK;
     if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
         return fail(NEMO_ERR_INVALID, "nemo_solve: bad argument");
     if (check_cam(cam)) return NEMO_ERR_INVALID;
     if (dof != 3 && dof != 4 && dof != 6) return fail(NEMO_ERR_INVALID, "nemo_solve: dof must be 3, 4 or 6");
     if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve: negative step count");
-    if (n_hyp == 0) return NEMO_OK;
     SolveArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
     a.rc.outward = m->faces_outward != nullptr;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     // LDS plan: for the whole handle, or for its largest part when every hypothesis renders one part
-    int lay_v = m->V, lay_f = m->F;
+    int lay_v = m->V, lay_f = m->F, lay_blocks = ((m->V - 1) >> 5) + 1;
     a.parts = nullptr; a.hyp_to_part = nullptr; a.n_parts = 1;
     if (hyp_to_part) {
         if (m->parts.empty()) return fail(NEMO_ERR_STATE, "nemo_solve_parts: the mesh has no parts (call nemo_mesh_set_parts)");
-        if (table_ranges || only) return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_parts: not available with partial tables");
-        lay_v = lay_f = 0;
-        for (const nemo::MeshPart& q : m->parts) { lay_v = q.nv > lay_v ? q.nv : lay_v; lay_f = q.nf > lay_f ? q.nf : lay_f; }
+        lay_v = lay_f = lay_blocks = 0;
+        for (const nemo::MeshPart& q : m->parts) {
+            lay_v = q.nv > lay_v ? q.nv : lay_v; lay_f = q.nf > lay_f ? q.nf : lay_f;
+            const int nb = ((q.v0 + q.nv - 1) >> 5) - (q.v0 >> 5) + 1;
+            lay_blocks = nb > lay_blocks ? nb : lay_blocks;
+        }
         a.parts = m->d_parts; a.hyp_to_part = hyp_to_part; a.n_parts = (int)m->parts.size();
     }
-    int rcode = plan_solve(cam->H, cam->W, lay_v, lay_f, kSolveThreads, m->aabb, &a.rc);
+    const int HW = cam->H * cam->W;
+    a.feat = feat; a.bank = nullptr; a.apiece = 0; a.meta = nullptr; a.nks = 0;
+    a.nfb = (lay_f + (1 << kFaceBlockShift) - 1) >> kFaceBlockShift;
+    int vblocks = 0;
+    if (feat) {
+        if (!m->bank_frag)
+            return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_features: %d channels (the on-demand table takes 16, 32, 64 or 128: use "
+                        "nemo_similarity_table + nemo_solve)", m->C);
+        // (pixel tile, face block) pairs travel as two 16-bit halves of a word
+        if (((HW + 31) >> 5) >= 0xFFFF || a.nfb > 0xFFFF) return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_features: map or mesh too large");
+        vblocks = lay_blocks;
+        a.meta = (const BankMeta*)m->bank_frag;
+        a.bank = (const uint4*)((const char*)m->bank_frag + SG_META_BYTES);
+        a.nks = m->C / 16;
+        a.apiece = (size_t)nemo::split_bank_blocks(m->V) * a.nks * 64;
+    }
+    int rcode = plan_solve(cam->H, cam->W, lay_v, lay_f, kSolveThreads, m->aabb, &a.rc, vblocks);
     if (rcode) return rcode;
     a.table_vg = (m->V + 3) >> 2;
     a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
@@ -1387,15 +1413,8 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* table,
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
     a.out_pose = out_pose; a.out_hist = out_hist;
     a.tscale = 1.0f; a.inv_tscale = 0.0f;
-    a.ranges = table_ranges; a.miss = miss_flags; a.only = only; a.nvb = nemo::split_bank_blocks(m->V);
-    if (table_ranges) {
-        if (!miss_flags) return fail(NEMO_ERR_INVALID, "nemo_solve_partial: table_ranges need miss_flags");
-        if (hyp_to_image) return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_partial: one hypothesis per image (no hyp_to_image)");
-        if (a.nvb > kNeedBlocks || !m->bank_frag)
-            return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_partial: at most %d vertices and a channel count of 16, 32, 64 or 128", 32 * kNeedBlocks);
-    }
-    auto kern = table_ranges ? (a.rc.L.faces >= 0 ? solve_kernel<true, false, true> : solve_kernel<false, false, true>)
-                             : (a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>);
+    auto kern = feat ? (a.rc.L.faces >= 0 ? solve_kernel<true, false, true> : solve_kernel<false, false, true>)
+                     : (a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>);
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -1407,8 +1426,8 @@ extern "C" int nemo_solve(nemo_mesh_t m, const nemo_camera* cam, const float* ta
                           const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
                           int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
                           void* stream) {
-    return solve_impl(m, cam, table, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
-                      global_batch, dof, opt, out_pose, out_hist, nullptr, nullptr, nullptr, nullptr, stream);
+    return solve_impl(m, cam, nullptr, const_cast<float*>(table), clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes,
+                      n_hyp, n_img, global_batch, dof, opt, out_pose, out_hist, nullptr, stream);
 }
 
 extern "C" int nemo_solve_parts(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
@@ -1417,18 +1436,26 @@ extern "C" int nemo_solve_parts(nemo_mesh_t m, const nemo_camera* cam, const flo
                                 int32_t n_img, int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose,
                                 float* out_hist, void* stream) {
     if (!hyp_to_part) return fail(NEMO_ERR_INVALID, "nemo_solve_parts: hyp_to_part is required (nemo_solve renders the whole handle)");
-    return solve_impl(m, cam, table, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
-                      global_batch, dof, opt, out_pose, out_hist, nullptr, nullptr, nullptr, hyp_to_part, stream);
+    return solve_impl(m, cam, nullptr, const_cast<float*>(table), clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes,
+                      n_hyp, n_img, global_batch, dof, opt, out_pose, out_hist, hyp_to_part, stream);
 }
 
-extern "C" int nemo_solve_partial(nemo_mesh_t m, const nemo_camera* cam, const float* table, const float* clu,
-                                  const float* init_campos, const float* init_theta, const float* init_principal,
-                                  const int32_t* score_boxes, int32_t n_img, int32_t global_batch, int32_t dof,
-                                  const nemo_adam* opt, const int32_t* table_ranges, int32_t* miss_flags,
-                                  const int32_t* only_flagged, float* out_pose, float* out_hist, void* stream) {
-    if (!table_ranges && !only_flagged) return fail(NEMO_ERR_INVALID, "nemo_solve_partial: table_ranges or only_flagged");
-    return solve_impl(m, cam, table, clu, nullptr, init_campos, init_theta, init_principal, score_boxes, n_img, n_img, global_batch,
-                      dof, opt, out_pose, out_hist, table_ranges, miss_flags, only_flagged, nullptr, stream);
+extern "C" size_t nemo_solve_features_workspace(nemo_mesh_t m, int32_t n_img, int32_t HW) {
+    if (!m || n_img <= 0 || HW <= 0 || !m->bank_frag) return 0;
+    return align256((size_t)n_img * table_image_elems(m->V, HW) * sizeof(float));
+}
+
+extern "C" int nemo_solve_features(nemo_mesh_t m, const nemo_camera* cam, const float* feat, void* workspace, size_t workspace_bytes,
+                                   const float* clu, const int32_t* hyp_to_image, const int32_t* hyp_to_part,
+                                   const float* init_campos, const float* init_theta, const float* init_principal,
+                                   const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
+                                   const nemo_adam* opt, float* out_pose, float* out_hist, void* stream) {
+    if (!feat || !workspace) return fail(NEMO_ERR_INVALID, "nemo_solve_features: feat and workspace are required");
+    if (m && m->bank_frag && n_img > 0 && cam && workspace_bytes < nemo_solve_features_workspace(m, n_img, cam->H * cam->W))
+        return fail(NEMO_ERR_INVALID, "nemo_solve_features: workspace of %zu bytes required, %zu given",
+                    nemo_solve_features_workspace(m, n_img, cam->H * cam->W), workspace_bytes);
+    return solve_impl(m, cam, feat, (float*)workspace, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
+                      global_batch, dof, opt, out_pose, out_hist, hyp_to_part, stream);
 }
 
 // Refinement of the keypoint-initialised solver (solve_pose.py:220-324): every proposal of an image is one
@@ -1451,8 +1478,8 @@ extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const floa
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
     if (rcode) return rcode;
-    a.table = table; a.clu = clu; a.hyp_to_image = hyp_to_image;
-    a.ranges = nullptr; a.miss = nullptr; a.only = nullptr; a.nvb = 0;
+    a.table = const_cast<float*>(table); a.clu = clu; a.hyp_to_image = hyp_to_image;
+    a.feat = nullptr; a.bank = nullptr; a.apiece = 0; a.meta = nullptr; a.nks = 0; a.nfb = 0;
     a.parts = nullptr; a.hyp_to_part = nullptr; a.n_parts = 1; a.table_vg = (m->V + 3) >> 2;
     a.init_campos = init_campos; a.init_theta = init_theta; a.init_principal = init_flow;
     a.score_boxes = nullptr;
@@ -1556,88 +1583,10 @@ extern "C" int nemo_similarity_table(nemo_mesh_t m, const float* feat, int32_t B
     if (B == 0) return NEMO_OK;
     if (!m || !feat || !table || B < 0 || HW <= 0) return fail(NEMO_ERR_INVALID, "nemo_similarity_table: bad argument");
     if (!m->memory_t) return fail(NEMO_ERR_STATE, "nemo_similarity_table: mesh has no vertex memory");
-    const int rc = m->bank_frag ? nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, nullptr, nullptr, (hipStream_t)stream)
+    const int rc = m->bank_frag ? nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, (hipStream_t)stream)
                                 : nemo::launch_table_gemm(m->memory_t, feat, table, m->V, m->C, HW, B, (hipStream_t)stream);
     if (rc)
         return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table: too many tiles for one launch");
-    HIP_TRY(hipGetLastError());
-    return NEMO_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// partial similarity tables
-// ------------------------------------------------------------------------------------------
-// The optimisation loop reads a table entry (vertex, pixel) only where a face of that vertex covers the pixel
-// during some step.  For every image and 32-vertex block, table_ranges_kernel projects the block's vertices at
-// the starting pose and returns the 128-pixel tiles of the rows they fall in, widened by margin_rows: the table
-// kernel computes only those (tile, block) products, and the solve kernel raises a flag for a hypothesis whose
-// faces leave the ranges (raster_direct), which the caller then repeats on a complete table.
-struct RangeArgs {
-    const float* verts; int V, nvb; CamConst cc;
-    const float* campos; const float* theta; const float* principal;
-    float def_px, def_py, focal; int margin;
-    int32_t* out;
-};
-
-__global__ __launch_bounds__(256) void table_ranges_kernel(RangeArgs a) {
-    __shared__ PoseCam pc;
-    __shared__ int lo[kNeedBlocks], hi[kNeedBlocks];
-    const int n = blockIdx.x, H = a.cc.H, W = a.cc.W;
-    const float py = a.principal ? a.principal[2 * n + 1] : a.def_py;
-    if (threadIdx.x == 0) {
-        float C[3] = {a.campos[3 * n], a.campos[3 * n + 1], a.campos[3 * n + 2]};
-        pose_setup(a.cc, C, a.theta[n], a.principal ? a.principal[2 * n] : a.def_px, py, &pc);
-    }
-    for (int k = threadIdx.x; k < a.nvb; k += blockDim.x) { lo[k] = H; hi[k] = -1; }
-    __syncthreads();
-    for (int v = threadIdx.x; v < a.V; v += blockDim.x) {
-        float Xv[3], xn, yn;
-        project_vertex(a.cc, pc.R, pc.T, pc.bx, pc.by, a.verts[3 * v], a.verts[3 * v + 1], a.verts[3 * v + 2], Xv, &xn, &yn);
-        int r0 = 0, r1 = H - 1;                              // a vertex at or behind the camera plane: every row
-        if (Xv[2] > 1e-3f) {
-            const float row = py - a.focal * Xv[1] / Xv[2];  // feature-map row of the projected vertex
-            if (row == row) {
-                r0 = (int)fminf(fmaxf(floorf(row) - (float)a.margin, 0.0f), (float)(H - 1));
-                r1 = (int)fminf(fmaxf(floorf(row) + 1.0f + (float)a.margin, 0.0f), (float)(H - 1));
-            }
-        }
-        atomicMin(&lo[v >> 5], r0);
-        atomicMax(&hi[v >> 5], r1);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < a.nvb; k += blockDim.x) {
-        int32_t* o = a.out + ((size_t)n * a.nvb + k) * 2;
-        if (hi[k] < lo[k]) { o[0] = 1; o[1] = 0; }           // a block of padding rows: never read
-        else { o[0] = (lo[k] * W) >> 7; o[1] = (hi[k] * W + W - 1) >> 7; }
-    }
-}
-
-extern "C" int32_t nemo_table_range_blocks(nemo_mesh_t m) { return m ? nemo::split_bank_blocks(m->V) : 0; }
-
-extern "C" int nemo_table_ranges(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
-                                 const float* principal, int32_t n, int32_t margin_rows, int32_t* out_ranges, void* stream) {
-    if (n == 0) return NEMO_OK;
-    if (!m || !campos || !theta || !out_ranges || n < 0 || margin_rows < 0) return fail(NEMO_ERR_INVALID, "nemo_table_ranges: bad argument");
-    if (check_cam(cam)) return NEMO_ERR_INVALID;
-    RangeArgs a;
-    a.verts = m->verts; a.V = m->V; a.nvb = nemo::split_bank_blocks(m->V);
-    if (a.nvb > kNeedBlocks) return fail(NEMO_ERR_UNSUPPORTED, "nemo_table_ranges: at most %d vertices", 32 * kNeedBlocks);
-    a.cc = make_cam_const(cam->H, cam->W, cam->focal);
-    a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py; a.focal = cam->focal;
-    a.margin = margin_rows; a.out = out_ranges;
-    hipLaunchKernelGGL(table_ranges_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
-    HIP_TRY(hipGetLastError());
-    return NEMO_OK;
-}
-
-extern "C" int nemo_similarity_table_partial(nemo_mesh_t m, const float* feat, int32_t B, int32_t HW, const int32_t* table_ranges,
-                                             const int32_t* only_flagged, float* table, void* stream) {
-    if (B == 0) return NEMO_OK;
-    if (!m || !feat || !table || B < 0 || HW <= 0 || (!table_ranges && !only_flagged))
-        return fail(NEMO_ERR_INVALID, "nemo_similarity_table_partial: bad argument");
-    if (!m->bank_frag) return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table_partial: channel count must be 16, 32, 64 or 128");
-    if (nemo::launch_split_table(m->bank_frag, feat, table, m->V, m->C, HW, B, table_ranges, only_flagged, (hipStream_t)stream))
-        return fail(NEMO_ERR_UNSUPPORTED, "nemo_similarity_table_partial: too many tiles for one launch");
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

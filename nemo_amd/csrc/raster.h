@@ -33,6 +33,7 @@
 //                      queue, no second pass; the covered entries are compacted in place (compact_covered32).
 #pragma once
 #include "geom.h"
+#include "split_f16.h"
 
 #pragma clang fp contract(off)
 
@@ -68,7 +69,13 @@ struct LdsLayout {
     int opt;                    // optimiser state (solve kernel) + queue counter
     int sched;                  // float2 [kSchedSteps]: per-step Adam step size and sqrt of the second bias correction
     int flist;                  // u16 [F]: faces that look at the camera this step (optimisation loop; -1: not kept)
-    int need;                   // u32 [kNeedBlocks]: per 32-vertex block the pixel tiles its table rows exist for (optimisation loop; -1: none)
+    // optimisation loop computing the similarity table on demand (-1 / 0: not kept)
+    int mask_words;             // 32-bit words of a vertex-block mask (one bit per 32-vertex block the mesh can span)
+    int present;                // u32 [32-pixel tiles][mask_words]: bit (pixel tile, vertex block) = that tile of the table has been computed
+    int present_fb, fb_words;   // u32 [fb_words]: bit (pixel tile, block of faces) = every table tile a face of the block can read there is present
+    int fbmask;                 // u32 [face blocks][mask_words]: the vertex blocks the faces of a face block use
+    int wmask;                  // u32 [waves][mask_words]: per wave, the vertex blocks to compute for one pixel tile
+    int od_words;               // words from `present` on (cleared at set-up)
     int total;
 };
 
@@ -95,7 +102,7 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
     L.opt = o; o = align16(o + 256);
     L.sched = o; o = align16(o + 8 * kSchedSteps);
     L.flist = -1;
-    L.need = -1;
+    L.mask_words = 0; L.present = L.present_fb = L.fbmask = L.wmask = -1; L.fb_words = 0; L.od_words = 0;
     L.total = o;
     return L;
 }
@@ -103,9 +110,10 @@ inline LdsLayout make_layout(int H, int W, int V, int F, bool faces_in_lds, int 
 // Layout of the optimisation loop: 32-bit keys (quantised depth above the face index), the covered entries
 // are compacted in place into the key buffer (no queue) and a face is three 16-bit vertex indices.  Half the
 // size of the layout above, so that two workgroups share a compute unit.
-constexpr int kNeedBlocks = 256;          // partial similarity tables: at most this many 32-vertex blocks (block ids travel as bytes)
 constexpr int kPackedFaceVerts = 1 << 16;     // faces are kept in LDS only when the vertex indices fit 16 bits
-inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds, int waves) {
+constexpr int kFaceBlockShift = 5;            // faces per face block of the on-demand presence map: 32
+// vblocks > 0: with the presence maps of the on-demand similarity table, for a mesh that spans at most that many 32-vertex blocks.
+inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds, int waves, int vblocks = 0) {
     LdsLayout L;
     L.waves = waves;
     const int chunks = (H * W + 63) / 64;
@@ -122,7 +130,18 @@ inline LdsLayout make_solve_layout(int H, int W, int V, int F, bool faces_in_lds
     L.opt = o; o = align16(o + 256);
     L.sched = o; o = align16(o + 8 * kSchedSteps);
     if (F < (1 << 16)) { L.flist = o; o = align16(o + 2 * F); } else L.flist = -1;
-    L.need = o; o = align16(o + 4 * kNeedBlocks);
+    L.mask_words = 0; L.present = L.present_fb = L.fbmask = L.wmask = -1; L.fb_words = 0; L.od_words = 0;
+    if (vblocks > 0) {
+        const int npt32 = (H * W + 31) / 32, nfb = (F + (1 << kFaceBlockShift) - 1) >> kFaceBlockShift;
+        L.mask_words = (vblocks + 31) / 32;
+        L.fb_words = (npt32 * nfb + 31) / 32;
+        L.present = o;
+        L.present_fb = L.present + 4 * npt32 * L.mask_words;
+        L.fbmask = L.present_fb + 4 * L.fb_words;
+        L.wmask = L.fbmask + 4 * nfb * L.mask_words;
+        L.od_words = npt32 * L.mask_words + L.fb_words + nfb * L.mask_words + waves * L.mask_words;
+        o = align16(o + 4 * L.od_words);
+    }
     L.total = o;
     return L;
 }
@@ -164,8 +183,7 @@ struct Lds {
     unsigned int* queue;
     unsigned int* qcount;    // [4]: render kernels: pairs in the near / far half; optimisation loop: row range, task counter, front faces
     unsigned short* flist;   // optimisation loop: front-face list or nullptr
-    unsigned int* need;      // optimisation loop with a partial table: first | last << 16 pixel tile per 32-vertex block, or nullptr
-    int* miss;               // global flag of this hypothesis: set when a face needs a table tile outside those ranges
+    unsigned int *present, *present_fb, *fbmask, *wmask;   // on-demand similarity table (see LdsLayout) or nullptr
     PoseCam* pc;
     char* opt;
 };
@@ -184,8 +202,10 @@ __device__ inline Lds carve(char* base, const LdsLayout& L) {
     s.opt = base + L.opt;
     s.qcount = (unsigned int*)(base + L.opt + 240);
     s.flist = L.flist >= 0 ? (unsigned short*)(base + L.flist) : nullptr;
-    s.need = L.need >= 0 ? (unsigned int*)(base + L.need) : nullptr;
-    s.miss = nullptr;
+    s.present = L.present >= 0 ? (unsigned int*)(base + L.present) : nullptr;
+    s.present_fb = L.present >= 0 ? (unsigned int*)(base + L.present_fb) : nullptr;
+    s.fbmask = L.present >= 0 ? (unsigned int*)(base + L.fbmask) : nullptr;
+    s.wmask = L.present >= 0 ? (unsigned int*)(base + L.wmask) : nullptr;
     return s;
 }
 
@@ -259,6 +279,8 @@ __device__ inline void solve_prologue(const RasterCtx& rc, const Lds& s) {
                                      (unsigned)(rc.faces[3 * i + 2] - rc.vbase));
     const int slots = ((H * W + 63) >> 6) << 6;
     for (int p = threadIdx.x; p < slots; p += blockDim.x) s.zkey[p] = kEmptyKey32;
+    if (s.present)
+        for (int i = threadIdx.x; i < rc.L.od_words; i += blockDim.x) s.present[i] = 0u;
     if (threadIdx.x == 0) { s.qcount[0] = 0; s.qcount[1] = 0; }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s.red[i] = 0.0f;
     __syncthreads();
@@ -667,8 +689,7 @@ __device__ inline void walk_step(WalkState& w, int k, unsigned int* zkey, float 
 // index and takes the next one from an LDS counter (s.qcount[2], which the caller keeps at the number
 // of waves between steps), so waves whose faces have small boxes pick up more tasks.  The caller keeps
 // s.qcount[3] (length of the list) at 0 between steps.
-// PARTIAL: the similarity table exists only for the tile ranges in s.need; a face that needs more sets *s.miss.
-template <bool FACES_LDS, bool PARTIAL>
+template <bool FACES_LDS>
 __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     WalkGrid g;
     g.H = rc.cc.H; g.W = rc.cc.W;
@@ -718,8 +739,6 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     // the vertex records of the next task are requested before the pixel walk of the current one
     FaceVerts nfv;
     int nf = 0;
-    unsigned int nblk = 0;                      // 32-vertex blocks of the face's vertices, a byte each (partial tables)
-    bool miss = false;
     {
         const int idx = task * 64 + lane;
         int i0 = 0, i1 = 0, i2 = 0;
@@ -728,13 +747,11 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
             load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
         }
         nfv = face_verts(s, i0, i1, i2);
-        if (PARTIAL) nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
     }
     while (task < ntask) {
         const bool valid = task * 64 + lane < nfaces;
         const int f = nf;
         const FaceVerts fv = nfv;
-        const unsigned int blk = nblk;
         unsigned int nt = 0;
         if (lane == 0) nt = atomicAdd(&s.qcount[2], 1u);
         const int next = (int)__builtin_amdgcn_readfirstlane(nt);
@@ -746,7 +763,6 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
                 load_face2<FACES_LDS>(rc, s, nf, &i0, &i1, &i2);
             }
             nfv = face_verts(s, i0, i1, i2);
-            if (PARTIAL) nblk = (unsigned)(i0 >> 5) | (unsigned)(i1 >> 5) << 8 | (unsigned)(i2 >> 5) << 16;
         }
         WalkState w;
         int box[4];
@@ -754,16 +770,6 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
         if (w.n > 0 || slow) {
             const int r0 = g.H - 1 - box[3], r1 = g.H - 1 - box[1];
             row_lo = min(row_lo, r0); row_hi = max(row_hi, r1);
-            if (PARTIAL) {
-                // partial table: the pixels this face can cover lie in rows [r0, r1]; the table rows of its three
-                // vertices must exist for the 128-pixel tiles of those rows
-                const int t0 = (r0 * g.W) >> 7, t1 = (r1 * g.W + g.W - 1) >> 7;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const unsigned int r = s.need[(blk >> (8 * j)) & 255u];
-                    miss |= t0 < (int)(r & 0xFFFFu) || t1 > (int)(r >> 16);
-                }
-            }
         }
         if (__any(slow)) {                       // rare: a face crossing the camera plane
             if (slow)
@@ -799,7 +805,6 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
 #endif
     // rows that can hold covered pixels: s.qcount[0] = first, s.qcount[1] = last + 1 (the caller keeps
     // them at H and 0 between steps)
-    if (PARTIAL && miss && s.miss) *s.miss = 1;
     row_lo = wave_min(row_lo); row_hi = wave_max(row_hi);
     if (lane == 0 && row_hi >= row_lo) {
         atomicMin(&s.qcount[0], (unsigned)row_lo);
@@ -905,19 +910,112 @@ __device__ inline int compact_covered(const RasterCtx& rc, const Lds& s, unsigne
     return count;
 }
 
-// Optimisation loop: the same compaction for 32-bit keys, in place.  Wave w owns the chunks c0 + w,
-// c0 + w + waves, ... of the touched rows; its j-th covered entry is written over the j-th slot of those
-// same chunks (slot j lives at chunk c0 + w + (j >> 6) * waves, lane j & 63), which it has already read:
-// the key buffer doubles as the entry list and no other wave touches these chunks before the next step.
-// The caller consumes the entries with the same slot arithmetic and leaves every slot empty again.
-// Returns the number of entries; *first_chunk = c0 + w.  No barrier.
+// ---- similarity-table tiles computed on demand (optimisation loop) -------------------------------------------
+// The loop reads table entry (vertex, pixel) only where a face of that vertex covers the pixel, about one entry
+// in a hundred over 300 steps, so a wave computes the table itself, a tile of 32 vertices x 32 pixels at a time,
+// the first time one of its covered pixels needs it: the same matrix-core product as the table kernel
+// (split_table_kernel: two-piece f16 operands, piece pairs (l,h) (h,l) (h,h) per 16-channel step, f32
+// accumulation), with the same operand values in the same order, so an entry is bit for bit what the table kernel
+// would have written.  The vertex bank's operand arrives as ready fragments from the mesh handle; the image's is
+// read from the feature map and split in registers (scale_clamp, split8, as the table kernel's first phase does),
+// once per call: all the tiles a pixel tile needs are computed together.
+struct TileCtx {
+    const float* feat;        // feature map of this hypothesis's image, [C, HW]
+    int HW;
+    float* table;             // its table ([pixel tile of 128][vertex group of 4][128][4])
+    const uint4* bank;        // the vertex bank as f16-piece fragments (first piece; the second follows at `apiece`)
+    size_t apiece;
+    float unscale;
+    int nks;                  // 16-channel steps (C / 16)
+    int vg_n;
+    int vb_first, nvb;        // the 32-vertex blocks the rendered mesh (part) spans
+    int nfb;                  // face blocks of the mesh (part): the face-block presence map's row length in bits
+};
+
+template <int NKS>
+__device__ inline void table_tiles_nks(const float* __restrict__ col, size_t HW, bool pok, const uint4* __restrict__ ap, size_t apiece,
+                                       float4* __restrict__ out, float us, int g0, int vg_n, int nvb, const unsigned int* vbmask) {
+    // the image's operand: all channel steps of the 32 pixels, both pieces, resident for the whole call (all of it
+    // requested at once: the eight values of a channel step turn into the eight registers of its two pieces)
+    uint4 b[NKS][SG_NP];
+    constexpr int NB = NKS;
+#pragma unroll
+    for (int k0 = 0; k0 < NKS; k0 += NB) {
+        float x[NB][8];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[i][j] = col[(size_t)((k0 + i) * 16 + j) * HW];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[i][j] = pok ? scale_clamp(x[i][j]) : 0.0f;
+            split8(x[i], b[k0 + i]);
+        }
+    }
+    constexpr int NA = NKS < 2 ? NKS : 2;       // channel steps of the bank's operand in flight
+    for (int w = 0; w * 32 < nvb; ++w) {
+        unsigned int todo = (unsigned)__builtin_amdgcn_readfirstlane((int)vbmask[w]);
+        while (todo) {
+            const int vb = w * 32 + __ffs((int)todo) - 1;
+            todo &= todo - 1;
+            const uint4* a = ap + (size_t)vb * NKS * 64;
+            f32x16 acc = {0};
+#pragma unroll
+            for (int k0 = 0; k0 < NKS; k0 += NA) {
+                uint4 ah[NA], al[NA];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) { ah[i] = a[(size_t)(k0 + i) * 64]; al[i] = a[apiece + (size_t)(k0 + i) * 64]; }
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(al[i]), as_frag(b[k0 + i][0]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(ah[i]), as_frag(b[k0 + i][1]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(ah[i]), as_frag(b[k0 + i][0]), acc, 0, 0, 0);
+                }
+            }
+            // result register quad j of a lane = vertices 32 vb + 8 j + 4 lk .. + 3 of pixel px: one 16-byte table element
+            float4* o = out + (size_t)vb * 8 * 128;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (g0 + vb * 8 + 2 * j < vg_n) o[(size_t)(2 * j) * 128] = make_float4(acc[4 * j] * us, acc[4 * j + 1] * us, acc[4 * j + 2] * us, acc[4 * j + 3] * us);
+        }
+    }
+}
+
+// The tiles (vertex block vb_first + v, pixel tile pt32) for every bit v set in vbmask (words in LDS).  A function of
+// its own (not inlined): its registers (the image's operand, the accumulators) are then not part of the optimisation
+// loop's allocation, which has none to spare; it is called off the loop's common path.
+__device__ __attribute__((noinline)) void table_tiles(const float* feat, const uint4* bank, float* table, int HW, int nks, int vg_n,
+                                                      size_t apiece, float unscale, int vb_first, int nvb, int pt32,
+                                                      const unsigned int* vbmask) {
+    const int lane = threadIdx.x & 63, lk = lane >> 5, px = lane & 31;
+    const int p = pt32 * 32 + px;
+    const bool pok = p < HW;
+    const float* col = feat + (pok ? p : HW - 1) + (size_t)(lk * 8) * HW;
+    const uint4* ap = bank + (size_t)vb_first * nks * 64 + lane;
+    const int g0 = vb_first * 8 + lk;            // vertex group of register quad 0 of the first block
+    float4* out = reinterpret_cast<float4*>(table) + ((size_t)(pt32 >> 2) * vg_n + g0) * 128 + (pt32 & 3) * 32 + px;
+    switch (nks) {
+        case 1: table_tiles_nks<1>(col, HW, pok, ap, apiece, out, unscale, g0, vg_n, nvb, vbmask); break;
+        case 2: table_tiles_nks<2>(col, HW, pok, ap, apiece, out, unscale, g0, vg_n, nvb, vbmask); break;
+        case 4: table_tiles_nks<4>(col, HW, pok, ap, apiece, out, unscale, g0, vg_n, nvb, vbmask); break;
+        default: table_tiles_nks<8>(col, HW, pok, ap, apiece, out, unscale, g0, vg_n, nvb, vbmask); break;
+    }
+}
+
+// Optimisation loop: the same compaction for 32-bit keys, in place.  Chunk c (64 consecutive pixels) belongs to
+// wave c % waves for the whole launch; a wave scans its chunks of the touched rows and writes its j-th covered
+// entry over the j-th slot of those same chunks (slot j lives at chunk first + (j >> 6) * waves, lane j & 63),
+// which it has already read: the key buffer doubles as the entry list and no other wave touches these chunks
+// before the next step.  The caller consumes the entries with the same slot arithmetic and leaves every slot
+// empty again.  Returns the number of entries; *first_chunk = the wave's first chunk.  No barrier.
 __device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int row0, int row1, int* first_chunk) {
     const int W = rc.cc.W, nw = rc.L.waves;
     const int c0 = (row0 * W) >> 6, c1 = (row1 * W + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int fmask = (1u << rc.face_bits) - 1u;
     const float inv_w = 1.0f / (float)W;
-    const int cw = c0 + wave;
+    const int cw = c0 + ((wave - c0 % nw) + nw) % nw;       // first chunk >= c0 owned by this wave
     int count = 0;
     constexpr int CB = 4;                       // chunks in flight per wave: their key reads overlap
     for (int cb = cw; cb < c1; cb += CB * nw) {
@@ -943,6 +1041,105 @@ __device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int r
     }
     *first_chunk = cw;
     return count;
+}
+
+// On-demand table, set-up (once per workgroup, after solve_prologue): the vertex blocks every face block uses.
+// Ends with a barrier.
+template <bool FACES_LDS>
+__device__ inline void build_face_block_masks(const RasterCtx& rc, const Lds& s, const TileCtx& tc) {
+    for (int f = threadIdx.x; f < rc.F; f += blockDim.x) {
+        int vi[3];
+        load_face2<FACES_LDS>(rc, s, f, &vi[0], &vi[1], &vi[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned int vb = (unsigned)(((rc.vbase + vi[k]) >> 5) - tc.vb_first);
+            atomicOr(&s.fbmask[(f >> kFaceBlockShift) * rc.L.mask_words + (vb >> 5)], 1u << (vb & 31u));
+        }
+    }
+    __syncthreads();
+}
+
+// On-demand table: a pass of each wave over its own compacted entries (dense lanes, four entries per lane in
+// flight, straight-line while nothing is missing).  One presence bit per (pixel tile, face block) says that every
+// table tile a face of that block can read at a pixel of that tile is there: the tiles (pixel tile, vertex block)
+// for all vertex blocks the face block uses.  Where bits are clear the wave takes one pixel tile at a time: it sets
+// the bits of all the face blocks missing there, gathers their vertex blocks, drops those whose tiles exist
+// (per-tile presence map) and computes the rest in one call.  A 32-pixel tile lies inside one chunk, so only the
+// wave that owns its pixels ever asks for, computes and reads its tiles: no barrier, no other wave waits.
+//
+// A function of its own (not inlined), with every operand passed by value: the pass then leaves the register
+// allocation of the optimisation loop as it is without it.
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+
+__device__ inline void ensure_table_tiles_call(lds_u32* zkey, lds_u32* present, lds_u32* present_fb, lds_u32* fbmask,
+                                                                  lds_u32* wmask, int W, int waves, int mw, int nfb, int first_chunk, int cnt,
+                                                                  const float* feat, const uint4* bank, float* table, int HW, int nks, int vg_n,
+                                                                  size_t apiece, float unscale, int vb_first, int nvb) {
+    constexpr unsigned int kNone = 0xFFFFFFFFu;
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int slot_step = 64 * waves;
+    const lds_u32* first = zkey + first_chunk * 64 + lane;       // always inside the key buffer
+    const lds_u32* slot = first;
+    wmask += (threadIdx.x >> 6) * mw;
+    bool computed = false;
+    // (trip count uniform over the wave: the rare path below needs every lane)
+    for (int ib0 = 0; ib0 < cnt; ib0 += 64 * U, slot += U * slot_step) {
+        unsigned int code[U];
+        bool miss = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = ib0 + lane + 64 * u < cnt;
+            const unsigned int e = *(ok ? slot + u * slot_step : first);    // unconditional read; a lane past the end ...
+            int px, py, f;
+            unpack_entry(ok ? e : 0u, &px, &py, &f);                        // ... looks at pixel 0 / face 0 and reports nothing
+            const unsigned int pt = (unsigned)(py * W + px) >> 5, fb = (unsigned)f >> kFaceBlockShift;
+            const unsigned int bit = pt * (unsigned)nfb + fb;
+            const bool absent = ok && !((present_fb[bit >> 5] >> (bit & 31u)) & 1u);
+            code[u] = absent ? (pt << 16 | fb) : kNone;
+            miss |= absent;
+        }
+        if (!__any(miss)) continue;
+        for (;;) {                                   // rare: one round per pixel tile with something missing
+            unsigned int mine = kNone;
+#pragma unroll
+            for (int u = 0; u < U; ++u) mine = min(mine, code[u]);
+            const unsigned long long pend = __ballot(mine != kNone);
+            if (!pend) break;
+            const unsigned int pt = (unsigned)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)pend) - 1) >> 16;
+            for (int w = lane; w < mw; w += 64) wmask[w] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (code[u] != kNone && (code[u] >> 16) == pt) {
+                    const unsigned int fb = code[u] & 0xFFFFu, bit = pt * (unsigned)nfb + fb;
+                    code[u] = kNone;
+                    __hip_atomic_fetch_or(&present_fb[bit >> 5], 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int w = 0; w < mw; ++w)
+                        __hip_atomic_fetch_or(&wmask[w], fbmask[fb * mw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            bool some = false;
+            for (int w = lane; w < mw; w += 64) {
+                const unsigned int have = present[pt * mw + w], need = wmask[w] & ~have;
+                present[pt * mw + w] = have | need;
+                wmask[w] = need;
+                some |= need != 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (__any(some)) {
+                table_tiles(feat, bank, table, HW, nks, vg_n, apiece, unscale, vb_first, nvb, (int)pt, (const unsigned int*)wmask);
+                computed = true;
+            }
+        }
+    }
+    if (computed) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the tile stores have landed before the wave reads them
+}
+
+__device__ inline void ensure_table_tiles(const RasterCtx& rc, const Lds& s, const TileCtx& tc, int first_chunk, int cnt) {
+    ensure_table_tiles_call((lds_u32*)s.zkey, (lds_u32*)s.present, (lds_u32*)s.present_fb, (lds_u32*)s.fbmask, (lds_u32*)s.wmask, rc.cc.W,
+                            rc.L.waves, rc.L.mask_words, tc.nfb, first_chunk, cnt, tc.feat, tc.bank, tc.table, tc.HW, tc.nks, tc.vg_n,
+                            tc.apiece, tc.unscale, tc.vb_first, tc.nvb);
 }
 
 }  // namespace nemo

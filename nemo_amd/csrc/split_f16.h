@@ -46,6 +46,11 @@ __device__ inline void split8(const float x[8], uint4 out[SG_NP]) {
     out[1] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// Header of the vertex bank's fragment buffer (first 256 bytes): largest |memory| as float bits, the power-of-two
+// scale applied to the bank, and the factor that undoes both scales on a product.
+struct BankMeta { uint32_t absmax_bits; float scale; float unscale; };
+constexpr size_t SG_META_BYTES = 256;
+
 __device__ inline f16x8 as_frag(const uint4& u) {
     union { uint4 u; f16x8 f; } c; c.u = u; return c.f;
 }

@@ -151,11 +151,6 @@ int launch_table_gemm(const float* memT, const float* feat, float* table, int V,
 constexpr int SG_PT = 128;          // pixels per workgroup
 constexpr int SG_THREADS = 256;     // 4 waves, each a 32-vertex block x all 128 pixels at a time
 
-// Header of the bank fragment buffer (first 256 bytes): largest |memory| as float bits, the power-of-two
-// scale applied to the bank, and the factor that undoes both scales on the result.
-struct BankMeta { uint32_t absmax_bits; float scale; float unscale; };
-constexpr size_t SG_META_BYTES = 256;
-
 __global__ void bank_absmax_kernel(const float* __restrict__ memory, size_t n, BankMeta* meta) {
     float m = 0.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -285,23 +280,11 @@ template <int NKS>
 __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const BankMeta* __restrict__ meta,
                                                                     const uint4* __restrict__ bank_frag,
                                                                     const float* __restrict__ feat, float* __restrict__ table,
-                                                                    int V, int nvb, int HW, int npt,
-                                                                    const int32_t* __restrict__ ranges,
-                                                                    const int32_t* __restrict__ only) {
+                                                                    int V, int nvb, int HW, int npt) {
     extern __shared__ __align__(16) char sg_lds[];
     using W = SplitWave<NKS>;
     constexpr int C = W::C, row_bytes = W::row_bytes, piece_bytes = W::piece_bytes;
     const int pt = blockIdx.x % npt, b = blockIdx.x / npt;
-    // Partial tables: `only` keeps the images whose entry is non-zero (they get the whole table); otherwise
-    // `ranges` [B][nvb][2] names, per 32-vertex block, the first and last pixel tile that will be read.
-    if (only && only[b] == 0) return;
-    const int32_t* rg = (ranges && !only) ? ranges + (size_t)b * nvb * 2 : nullptr;
-    auto needed = [&](int x) { return !rg || (pt >= rg[2 * x] && pt <= rg[2 * x + 1]); };
-    if (rg) {
-        bool any = false;
-        for (int x = 0; x < nvb; ++x) any |= needed(x);
-        if (!any) return;                     // uniform over the workgroup: no block reads this pixel tile
-    }
     const int p0 = pt * SG_PT;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* fb = feat + (size_t)b * C * HW;
@@ -350,7 +333,6 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const BankMeta*
 
     constexpr int WAVES = SG_THREADS / 64;
     int vb = wave;
-    while (vb < nvb && !needed(vb)) vb += WAVES;
     if (vb >= nvb) return;
     // The vertex list ends less than 64 rows before the end of the last block pair, so only the last block
     // of a wave can hang over it, and the last block is stored by the checked epilogue: every block stored
@@ -365,7 +347,6 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const BankMeta*
     int prev_v0 = vb * 32;
     for (;;) {
         vb += WAVES;
-        while (vb < nvb && !needed(vb)) vb += WAVES;
         if (vb >= nvb) break;
         f32x16 acc[4] = {};
         w.template tile_mma<true>(vb, acc, o, prev_v0);
@@ -391,8 +372,7 @@ void launch_split_bank(const float* memory, void* buf, int V, int C, hipStream_t
 }
 
 template <int NKS>
-static void launch_split_nks(const void* buf, const float* feat, float* table, int V, int HW, int B, int npt, const int32_t* ranges,
-                             const int32_t* only, hipStream_t st) {
+static void launch_split_nks(const void* buf, const float* feat, float* table, int V, int HW, int B, int npt, hipStream_t st) {
     const BankMeta* meta = (const BankMeta*)buf;
     const uint4* frag = (const uint4*)((const char*)buf + SG_META_BYTES);
     constexpr int lds = SG_NP * SG_PT * (NKS * 16 * 2 + 16);
@@ -404,18 +384,17 @@ static void launch_split_nks(const void* buf, const float* feat, float* table, i
         attr_done[dev] = true;
     }
     hipLaunchKernelGGL(split_table_kernel<NKS>, dim3((unsigned)(npt * B)), dim3(SG_THREADS), lds, st, meta, frag, feat, table, V,
-                       split_bank_blocks(V), HW, npt, ranges, only);
+                       split_bank_blocks(V), HW, npt);
 }
 
-int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, const int32_t* ranges,
-                       const int32_t* only, hipStream_t st) {
+int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st) {
     const int npt = (HW + SG_PT - 1) / SG_PT;
     if ((long long)npt * B > 0x7FFFFFFFLL) return -1;
     switch (C / 16) {
-        case 1: launch_split_nks<1>(frag, feat, table, V, HW, B, npt, ranges, only, st); break;
-        case 2: launch_split_nks<2>(frag, feat, table, V, HW, B, npt, ranges, only, st); break;
-        case 4: launch_split_nks<4>(frag, feat, table, V, HW, B, npt, ranges, only, st); break;
-        case 8: launch_split_nks<8>(frag, feat, table, V, HW, B, npt, ranges, only, st); break;
+        case 1: launch_split_nks<1>(frag, feat, table, V, HW, B, npt, st); break;
+        case 2: launch_split_nks<2>(frag, feat, table, V, HW, B, npt, st); break;
+        case 4: launch_split_nks<4>(frag, feat, table, V, HW, B, npt, st); break;
+        case 8: launch_split_nks<8>(frag, feat, table, V, HW, B, npt, st); break;
         default: return -2;
     }
     return 0;

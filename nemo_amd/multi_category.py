@@ -9,8 +9,8 @@ What the reference does category by category:
 
 Here the category meshes live back to back in one mesh handle (ops.MeshHandle.set_parts) whose vertex memory is the
 bank's memory_pos as it is.  One clutter launch, one grid scoring per category (each category has its own
-pre-rendered grid), ONE similarity-table launch over all vertices and ONE solve launch over all (image, category)
-pairs, every pair a hypothesis with its own mesh (ops.solve(..., hyp_to_part=...)).  Every pair's result is what
+pre-rendered grid) and ONE solve launch over all (image, category) pairs (which computes the similarity-table tiles
+its covered pixels need itself), every pair a hypothesis with its own mesh (ops.solve(..., hyp_to_part=...)).  Every pair's result is what
 batch_solve_pose.solve_pose gives for that image on that category's own module with the same `global_batch`
 (bit for bit: a hypothesis only reads its own mesh, its own image and the loss normaliser).
 """
@@ -102,11 +102,16 @@ class MultiCategorySolver:
         boxes = None
         if bbox is not None:
             boxes = score_boxes_from_bbox(bbox, b, 1, down_sample_rate)[pair_image]
-        table = ops.similarity_table(self.mesh, fm)
-        pose, _ = ops.solve(self.mesh, self.camera(), table, clutter_score, init_C, init_theta, init_principal,
-                            hyp_to_image=pair_image.to(torch.int32), hyp_to_part=pair_category.to(torch.int32),
-                            global_batch=b if global_batch is None else int(global_batch), dof=6 if self.dof == 6 else 3,
-                            steps=epochs, lr_every=epochs // 3 if epochs >= 3 else 0, score_boxes=boxes, **adam)
+        skw = dict(hyp_to_image=pair_image.to(torch.int32), hyp_to_part=pair_category.to(torch.int32),
+                   global_batch=b if global_batch is None else int(global_batch), dof=6 if self.dof == 6 else 3,
+                   steps=epochs, lr_every=epochs // 3 if epochs >= 3 else 0, score_boxes=boxes, **adam)
+        if ops.on_demand_table_supported(self.mesh):
+            # only the table tiles a pair's covered pixels need are computed (inside the solve): an image's table over
+            # all categories' vertices is never built
+            pose, _ = ops.solve_from_features(self.mesh, self.camera(), fm, clutter_score, init_C, init_theta, init_principal, **skw)
+        else:
+            table = ops.similarity_table(self.mesh, fm)
+            pose, _ = ops.solve(self.mesh, self.camera(), table, clutter_score, init_C, init_theta, init_principal, **skw)
         sph = ops.spherical_angles(pose[:, 0:3])
         host = torch.cat([pose, sph], dim=1).cpu().numpy()
         times["optimization_time"] = time.time() - t2

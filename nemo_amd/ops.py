@@ -425,87 +425,68 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
     return out, hist
 
 
-def table_ranges(mesh, cam, campos, theta, principal=None, margin_rows=8):
-    """Per image and 32-vertex block the pixel tiles the optimisation loop is expected to read, from the starting
-    poses: -> int32 [n, n_blocks, 2] (first, last 128-pixel tile; rows of the projected block widened by margin_rows)."""
-    lib = _lib.load()
-    cp, th, pr, n = _pose_args(campos, theta, principal)
-    out = torch.empty(n, int(lib.nemo_table_range_blocks(mesh.h)), 2, dtype=torch.int32, device=cp.device)
-    cc = cam.c()
-    with torch.cuda.device(cp.device):
-        check(lib.nemo_table_ranges(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, int(margin_rows), ptr(out, torch.int32),
-                                    stream_ptr()), "nemo_table_ranges")
-    return out
-
-
-def similarity_table_partial(mesh, feature_map, out, ranges=None, only_flagged=None):
-    """similarity_table restricted to the (tile, block) pairs of `ranges` (the rest of `out` keeps its old contents),
-    or, with only_flagged [B] int32, the complete table of the flagged images only."""
+def solve_from_features(mesh, cam, feature_map, clu, init_campos, init_theta, init_principal=None, hyp_to_image=None,
+                        global_batch=None, dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, lr_gamma=0.2, lr_every=None,
+                        history=False, score_boxes=None, hyp_to_part=None, workspace=None):
+    """solve() without a precomputed table: the kernel computes the table tiles its covered pixels need, when they first
+    need them (bit for bit the result of similarity_table + solve).  feature_map [n_img,C,H,W]; workspace: an optional
+    float32 tensor of table_shape(mesh, n_img, H * W) to reuse (it need not be initialised).
+    -> (pose [n_hyp,8], loss_hist [n_hyp,steps] or None)."""
     lib = _lib.load()
     fm = f32c(feature_map)
-    B, Cc, H, W = fm.shape
-    if Cc != mesh.C:
-        raise ValueError(f"feature map has {Cc} channels, vertex memory has {mesh.C}")
-    if tuple(out.shape) != table_shape(mesh, B, H * W) or not out.is_contiguous() or out.dtype != torch.float32:
-        raise ValueError("out must be a contiguous float32 tensor of shape table_shape(mesh, B, H * W)")
-    if ranges is not None and (ranges.dtype != torch.int32 or ranges.shape[0] != B or not ranges.is_contiguous()):
-        raise ValueError("ranges must be the int32 tensor table_ranges returned for these images")
-    if only_flagged is not None and (only_flagged.dtype != torch.int32 or only_flagged.numel() != B):
-        raise ValueError("only_flagged must be int32 [B]")
-    with torch.cuda.device(fm.device):
-        check(lib.nemo_similarity_table_partial(mesh.h, ptr(fm), B, H * W, ptr(ranges, torch.int32), ptr(only_flagged, torch.int32),
-                                                ptr(out), stream_ptr()), "nemo_similarity_table_partial")
-    return out
-
-
-def solve_partial(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, ranges=None, miss_flags=None,
-                  only_flagged=None, out=None, global_batch=None, dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8,
-                  lr_gamma=0.2, lr_every=None, score_boxes=None):
-    """solve() for one hypothesis per image on a partial table: with `ranges`, hypotheses whose faces leave the
-    ranges set miss_flags (int32 [n], zeroed by the caller) and their rows of the result are void; with only_flagged
-    only the flagged hypotheses run (rows of `out` of the others are kept).  -> pose [n, 8]."""
-    lib = _lib.load()
-    cp, th, pr, n = _pose_args(init_campos, init_theta, init_principal)
-    clu2 = f32c(clu).reshape(n, -1)
-    if tuple(table.shape) != table_shape(mesh, n, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
-        raise ValueError("table / clutter shapes do not match the mesh and camera")
-    for name, t in (("ranges", ranges), ("miss_flags", miss_flags), ("only_flagged", only_flagged)):
-        if t is not None and (t.dtype != torch.int32 or t.shape[0] != n or not t.is_contiguous()):
-            raise ValueError(f"{name} must be a contiguous int32 tensor with one entry per image")
-    if ranges is not None and miss_flags is None:
-        raise ValueError("ranges need miss_flags")
+    n_img, Cc, H, W = fm.shape
+    if Cc != mesh.C or (H, W) != (cam.H, cam.W):
+        raise ValueError("feature maps do not match the vertex memory / camera")
+    cp, th, pr, n_hyp = _pose_args(init_campos, init_theta, init_principal)
+    if hyp_to_image is None and n_hyp != n_img:
+        raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
+    h2i = _image_index(hyp_to_image, n_img, cp.device)
+    clu2 = f32c(clu).reshape(n_img, -1)
+    if clu2.shape[1] != H * W:
+        raise ValueError("clutter score map does not match the camera")
+    nbytes = solve_workspace_bytes(mesh, n_img, H * W)
+    if nbytes == 0:
+        raise RuntimeError(f"nemo_solve_features takes 16, 32, 64 or 128 channels, not {mesh.C}: use similarity_table + solve")
+    if workspace is None:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=fm.device)
+    elif workspace.dtype != torch.uint8 or workspace.numel() < nbytes or not workspace.is_contiguous():
+        raise ValueError(f"workspace must be a contiguous uint8 tensor of at least {nbytes} bytes")
     opt = NemoAdam(int(steps), int(lr_every if lr_every is not None else max(steps // 3, 0)), float(lr), float(betas[0]),
                    float(betas[1]), float(eps), float(lr_gamma))
-    if out is None:
-        out = torch.empty(n, 8, device=cp.device)
-    elif tuple(out.shape) != (n, 8) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise ValueError("out must be float32 [n, 8]")
-    boxes = None if score_boxes is None else score_boxes.to(device=cp.device, dtype=torch.int32).reshape(n, 4).contiguous()
+    out = torch.empty(n_hyp, 8, device=cp.device)
+    hist = torch.empty(n_hyp, steps, device=cp.device) if history else None
     cc = cam.c()
-    gb = int(global_batch if global_batch is not None else n)
+    gb = int(global_batch if global_batch is not None else n_img)
+    boxes = None if score_boxes is None else score_boxes.to(device=cp.device, dtype=torch.int32).reshape(n_hyp, 4).contiguous()
+    h2p = None
+    if hyp_to_part is not None:
+        h2p = hyp_to_part.to(device=cp.device, dtype=torch.int32).contiguous()
+        if h2p.numel() != n_hyp:
+            raise ValueError("hyp_to_part needs one entry per hypothesis")
     with torch.cuda.device(cp.device):
-        check(lib.nemo_solve_partial(mesh.h, C.byref(cc), ptr(table), ptr(clu2), ptr(cp), ptr(th), ptr(pr), ptr(boxes, torch.int32),
-                                     n, gb, int(dof), C.byref(opt), ptr(ranges, torch.int32), ptr(miss_flags, torch.int32),
-                                     ptr(only_flagged, torch.int32), ptr(out), None, stream_ptr()), "nemo_solve_partial")
-    return out
+        check(lib.nemo_solve_features(mesh.h, C.byref(cc), ptr(fm), ptr(workspace, torch.uint8), workspace.numel(), ptr(clu2), ptr(h2i, torch.int32),
+                                      ptr(h2p, torch.int32), ptr(cp), ptr(th), ptr(pr), ptr(boxes, torch.int32), n_hyp, n_img, gb,
+                                      int(dof), C.byref(opt), ptr(out), ptr(hist), stream_ptr()), "nemo_solve_features")
+    return out, hist
 
 
-def solve_on_partial_table(mesh, cam, feature_map, clu, init_campos, init_theta, init_principal=None, margin_rows=8, table=None,
-                           **solve_kw):
-    """The whole sequence: ranges from the starting poses, partial table, solve, and the repeat of the flagged images
-    on their complete table.  -> (pose [n, 8], miss_flags int32 [n]); bit for bit what similarity_table + solve give.
-    No host synchronisation: the repeat launches exit at once when nothing is flagged."""
-    fm = f32c(feature_map)
-    n = fm.shape[0]
-    if table is None:
-        table = torch.empty(table_shape(mesh, n, cam.H * cam.W), device=fm.device)
-    ranges = table_ranges(mesh, cam, init_campos, init_theta, init_principal, margin_rows)
-    flags = torch.zeros(n, dtype=torch.int32, device=fm.device)
-    similarity_table_partial(mesh, fm, table, ranges=ranges)
-    pose = solve_partial(mesh, cam, table, clu, init_campos, init_theta, init_principal, ranges=ranges, miss_flags=flags, **solve_kw)
-    similarity_table_partial(mesh, fm, table, only_flagged=flags)
-    solve_partial(mesh, cam, table, clu, init_campos, init_theta, init_principal, only_flagged=flags, out=pose, **solve_kw)
-    return pose, flags
+def solve_workspace_bytes(mesh, n_img, HW):
+    """Bytes of workspace solve_from_features needs for n_img images (0: channel count not supported)."""
+    return int(_lib.load().nemo_solve_features_workspace(mesh.h, int(n_img), int(HW)))
+
+
+def workspace_tables(mesh, workspace, n_img, HW):
+    """The table part of a solve_from_features workspace as a float32 view of table_shape (for inspection and tests)."""
+    shape = table_shape(mesh, n_img, HW)
+    n = 1
+    for d in shape:
+        n *= d
+    return workspace[:4 * n].view(torch.float32).view(shape)
+
+
+def on_demand_table_supported(mesh):
+    """True when solve_from_features takes this mesh's channel count (16, 32, 64 or 128)."""
+    return mesh.C in (16, 32, 64, 128)
 
 
 def keypoint_corr(mesh, table, kp_coords, kp_vis, px_samples, py_samples, down_sample_rate, H, W):

@@ -448,12 +448,13 @@ def test_full_size_batch_properties(full):
     assert errs[B // 2] < 0.5 and errs[int(B * 0.9)] < 2.0, errs
 
 
-@pytest.mark.parametrize("which,B,margin", [("full", 64, 28), ("full", 16, 0), ("small", 12, 1)])
-def test_partial_table_equals_complete_table(which, B, margin, request):
-    """The partial similarity table (only the pixel tiles a 32-vertex block is expected to meet, from the starting
-    pose) with the repeat of the hypotheses that left their ranges: every result row equals, bit for bit, the one
-    from the complete table.  With a generous margin nothing is flagged and most of the table is skipped; with no
-    margin and starts far from the answer hypotheses are flagged, repeated, and still equal."""
+@pytest.mark.parametrize("which,B,spread,dof", [("full", 64, 0.2, 3), ("full", 16, 0.6, 3), ("small", 12, 0.6, 6)])
+def test_on_demand_table_equals_complete_table(which, B, spread, dof, request):
+    """The optimisation loop computing its similarity-table tiles itself, when a covered pixel first needs one
+    (nemo_solve_features): every result row and every step's loss equal, bit for bit, what the complete table
+    (nemo_similarity_table + nemo_solve) gives; every tile it wrote is the complete table's; most of the table is
+    never computed.  Starts near the answer and far from it, 3 and 6 degrees of freedom, and several hypotheses
+    sharing one image's workspace."""
     from nemo_amd import ops
     sc = request.getfixturevalue(which)
     dev = sc.device
@@ -468,32 +469,58 @@ def test_partial_table_equals_complete_table(which, B, margin, request):
     noise = torch.randn(fm.shape, generator=torch.Generator().manual_seed(16)).to(dev)
     fm = torch.nn.functional.normalize(fm + bg * clutter.view(1, -1, 1, 1) + 0.5 / math.sqrt(sc.C) * noise, dim=1).contiguous()
     clu = ops.clutter_score(fm, clutter)
-    spread = 0.2 if margin > 1 else 0.6                      # how far from the answer the optimisation starts
-    d = (torch.rand(B, 3, generator=g) - 0.5) * 2 * spread
+    d = (torch.rand(B, 3, generator=g) - 0.5) * 2 * spread    # how far from the answer the optimisation starts
     C0 = R.camera_position_from_spherical_angles(torch.full((B,), 5.0), gel + d[:, 1], gaz + d[:, 0]).to(dev)
     th0 = (gth + d[:, 2]).float().to(dev)
+    pr0 = (torch.tensor([[sc.W / 2, sc.H / 2]]) + 3.0 * (torch.rand(B, 2, generator=g) - 0.5)).to(dev) if dof == 6 else None
     cam = sc.mod.camera()
-    kw = dict(global_batch=B, steps=300, lr_every=100)
+    kw = dict(global_batch=B, steps=300, lr_every=100, dof=dof, history=True)
     tab = ops.similarity_table(sc.mod.mesh, fm)
-    dense, _ = ops.solve(sc.mod.mesh, cam, tab, clu, C0, th0, **kw)
-    table = torch.full(ops.table_shape(sc.mod.mesh, B, sc.H * sc.W), float("nan"), device=dev)   # stale contents must never matter
-    pose, flags = ops.solve_on_partial_table(sc.mod.mesh, cam, fm, clu, C0, th0, margin_rows=margin, table=table, **kw)
-    assert torch.equal(pose, dense)
-    ranges = ops.table_ranges(sc.mod.mesh, cam, C0, th0, margin_rows=margin)
-    npt = table.shape[1]
-    lo, hi = ranges[..., 0].clamp(min=0), ranges[..., 1].clamp(max=npt - 1)
-    frac = float((hi - lo + 1).clamp(min=0).sum()) / (B * ranges.shape[1] * npt)
-    n_flag = int(flags.sum())
-    if margin > 1:
-        assert n_flag == 0 and frac < 0.9, (n_flag, frac)
-        # the computed part is the complete table's, the rest was not touched
-        filled = ~torch.isnan(table)
-        assert torch.equal(table[filled], tab[filled]) and 0.2 < float(filled.float().mean()) < 0.92
-    else:
-        assert 0 < n_flag, (n_flag, frac)
-        assert torch.equal(table[flags.bool()], tab[flags.bool()])                                  # flagged images got their whole table
-    with pytest.raises(RuntimeError):
-        ops.solve_partial(sc.mod.mesh, cam, tab, clu, C0, th0)                                       # neither ranges nor flags
+    dense, dense_hist = ops.solve(sc.mod.mesh, cam, tab, clu, C0, th0, pr0, **kw)
+    ws = torch.empty(ops.solve_workspace_bytes(sc.mod.mesh, B, sc.H * sc.W), dtype=torch.uint8, device=dev)
+    work = ops.workspace_tables(sc.mod.mesh, ws, B, sc.H * sc.W)
+    work.fill_(float("nan"))                                  # stale contents must never matter
+    pose, hist = ops.solve_from_features(sc.mod.mesh, cam, fm, clu, C0, th0, pr0, workspace=ws, **kw)
+    assert torch.equal(pose, dense) and torch.equal(hist, dense_hist)
+    filled = ~torch.isnan(work)
+    frac = float(filled.float().mean())
+    assert torch.equal(work[filled], tab[filled]) and 0.005 < frac < 0.5, frac
+    # four hypotheses per image on a shared workspace (tiles written by several workgroups, identical values)
+    n = min(B, 8)
+    h2i = torch.arange(n, dtype=torch.int32).repeat_interleave(4)
+    dd = (torch.rand(4 * n, 3, generator=g) - 0.5) * 0.8
+    C4 = R.camera_position_from_spherical_angles(torch.full((4 * n,), 5.0), gel[:n].repeat_interleave(4) + dd[:, 1],
+                                                 gaz[:n].repeat_interleave(4) + dd[:, 0]).to(dev)
+    th4 = (gth[:n].repeat_interleave(4) + dd[:, 2]).float().to(dev)
+    kw4 = dict(global_batch=n, steps=120, lr_every=40, hyp_to_image=h2i)
+    ref4, _ = ops.solve(sc.mod.mesh, cam, tab[:n], clu[:n], C4, th4, **kw4)
+    work4 = ops.workspace_tables(sc.mod.mesh, ws, n, sc.H * sc.W)
+    work4.fill_(float("nan"))
+    got4, _ = ops.solve_from_features(sc.mod.mesh, cam, fm[:n], clu[:n], C4, th4, workspace=ws, **kw4)
+    assert torch.equal(got4, ref4)
+    filled = ~torch.isnan(work4)
+    assert torch.equal(work4[filled], tab[:n][filled])
+
+
+def test_on_demand_table_channel_counts(gpu):
+    """The on-demand form exists for 16, 32, 64 and 128 channels (the matrix-core table's); other counts are refused
+    with a message and the complete-table form takes them."""
+    from nemo_amd import ops
+    for C, ok in ((16, True), (64, True), (24, False)):
+        sc = Scene(24, 30, C, 100, 375.0 / 3, device=gpu)
+        fm, _ = sc.feature_maps(2, first_seed=3)
+        fmd = fm.to(gpu)
+        clu = ops.clutter_score(fmd, sc.clutter.to(gpu))
+        C0, th0 = random_poses(2, seed=8, dist=(4.8, 5.2))
+        tab = ops.similarity_table(sc.mod.mesh, fmd)
+        ref, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu, C0.to(gpu), th0.to(gpu), steps=40)
+        assert ops.on_demand_table_supported(sc.mod.mesh) == ok
+        if ok:
+            got, _ = ops.solve_from_features(sc.mod.mesh, sc.mod.camera(), fmd, clu, C0.to(gpu), th0.to(gpu), steps=40)
+            assert torch.equal(got, ref)
+        else:
+            with pytest.raises(RuntimeError, match="channels"):
+                ops.solve_from_features(sc.mod.mesh, sc.mod.camera(), fmd, clu, C0.to(gpu), th0.to(gpu), steps=40)
 
 
 # ---- committed golden fixtures (tests/golden, made by oracle/gen_golden.py) -----------------------------
