@@ -2,16 +2,18 @@
 """Benchmark of the render-and-compare pose solver (BASELINE.json configs[1]).
 
 One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
-clutter score -> pose-grid scoring (144 pre-rendered poses) -> similarity table -> 300 Adam steps for
-every image -> read-out (+ an RCCL all-gather of the [B,7] results when N > 1).  The CNN backbone is
-outside the path: feature maps are synthetic (seeded), the vertex bank is random-init.
+clutter score -> pose-grid scoring (144 pre-rendered poses) -> 300 Adam steps for every image (the solve
+computes the similarity-table tiles its covered pixels need itself) -> read-out (+ an RCCL all-gather of
+the [B,7] results when N > 1).  The CNN backbone is outside the path: feature maps are synthetic
+(seeded), the vertex bank is random-init.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # BASELINE configs[1], weak scaling
+    python bench.py --gpus N --strong --steps K --warmup W   # BASELINE configs[2]: 1024 images x 8 hypotheses, strong scaling
 
 N > 1 is launched by torch.distributed.run (one rank per GPU); every rank solves its own batch of
-`--batch` images (weak scaling), the loss normaliser uses the global batch size, rank 0 prints ONE
-JSON line.  `value` = hypothesis-optimisation steps per second of the whole job; images/s is in
-`images_per_sec`.
+`--batch` images (weak scaling; with --strong its 1/N share of 1024 images), the loss normaliser uses the
+global batch size, rank 0 prints ONE JSON line.  `value` = hypothesis-optimisation steps per second of the
+whole job; images/s is in `images_per_sec`.
 """
 import argparse
 import json
@@ -28,8 +30,11 @@ sys.path.insert(0, ROOT)
 H, W, C = 80, 100, 128           # 640x800 image at stride 8, 128 channels
 FOCAL = 3000.0 / 8
 EPOCHS = 300
-ALGO_BYTES_PER_HYP_STEP = C * H * W * 4 + H * W * 4     # feature map + clutter map read once per step
+STREAM_BYTES_PER_HYP_STEP = C * H * W * 4 + H * W * 4     # a design that streams the feature map + clutter map once per step
 HBM_PEAK_GBS = 8000.0
+MFMA_F16_PEAK_TFLOPS = 2500.0
+HALF_EXTENTS = (0.225, 0.5, 0.18)     # the synthetic cuboid: half of a car's 0.45 / 1.0 / 0.36, so that it fits the 100-pixel map at distance 5
+STRONG_TOTAL_IMAGES, STRONG_HYPOTHESES = 1024, 8
 
 
 def build_scene(dev, seed=0):
@@ -37,7 +42,8 @@ def build_scene(dev, seed=0):
     import nemo_amd
     from nemo_amd.utils import meshelize, normalize_features
     # cuboid mesh (V=1118, F=1904), vertices rounded through the OFF text format like the reference's files
-    v, f = meshelize((-0.225, 0.225), (-0.5, 0.5), (-0.18, 0.18), 1000)
+    hx, hy, hz = HALF_EXTENTS
+    v, f = meshelize((-hx, hx), (-hy, hy), (-hz, hz), 1000)
     v = np.array([[float("%.16f" % x) for x in row] for row in v], dtype=np.float32)
     g = torch.Generator().manual_seed(seed)
     mem = torch.nn.functional.normalize(torch.randn(v.shape[0], C, generator=g), dim=1)
@@ -96,8 +102,8 @@ def cpu_baseline(mod, mem, clutter, v, f, fm0, maps_dev, cs, ths, n_steps=EPOCHS
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=None, help="default 256 (8 with --strong)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 16 (1 with --strong)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 2: 64)")
     ap.add_argument("--in-flight", type=int, default=8,
                     help="batches processed together (a 64-image solve launch occupies an eighth of the chip; eight batches "
@@ -108,12 +114,19 @@ def main():
     ap.add_argument("--complete-table", action="store_true",
                     help="compute the complete vertex x pixel similarity table in front of the solve (nemo_similarity_table + "
                          "nemo_solve) instead of letting the solve compute the tiles it needs (nemo_solve_features, the default)")
+    ap.add_argument("--strong", action="store_true",
+                    help=f"BASELINE configs[2]: {STRONG_TOTAL_IMAGES} images x {STRONG_HYPOTHESES} hypotheses in total, sharded over the ranks "
+                         "(strong scaling: a step is one pass over all of them); overrides --batch, --hypotheses and --in-flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true",
                     help="let the groups on different launch streams start together (default: a group's clutter / grid / table "
                          "kernels start when the previous group's have finished, i.e. beside the previous group's solve)")
     args = ap.parse_args()
 
+    if args.steps is None:
+        args.steps = 8 if args.strong else 256
+    if args.warmup is None:
+        args.warmup = 1 if args.strong else 16
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,6 +134,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch through python -m torch.distributed.run --nproc-per-node N")
+    if args.strong:
+        if STRONG_TOTAL_IMAGES % world:
+            raise SystemExit(f"--strong shards {STRONG_TOTAL_IMAGES} images: the number of ranks ({world}) must divide it")
+        args.batch, args.hypotheses, args.in_flight = STRONG_TOTAL_IMAGES // world, STRONG_HYPOTHESES, 1
     # NEMO_BENCH_REHEARSAL=1: several ranks share the visible GPUs and talk over gloo, to rehearse the N > 1
     # code path on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
     rehearsal = os.environ.get("NEMO_BENCH_REHEARSAL") == "1"
@@ -170,7 +187,7 @@ def main():
     front_ev = [None]
     stagger = not args.no_stagger and n_streams > 1
 
-    def one_group(g, timed=False, host_out=None, slot=0):
+    def one_group(g, timed=False, host_out=None, slot=0, gather=True):
         """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major).
         slot: which stream's buffers to use (the caller has made that stream current)."""
         n = g * B
@@ -210,7 +227,7 @@ def main():
             pose = pose[torch.arange(n, device=dev), pose[:, :, 6].argmin(dim=1)]
         sph = ops.spherical_angles(pose[:, 0:3])
         res = torch.cat([sph[:, 2:3], sph[:, 1:2], pose[:, 3:4], sph[:, 0:1], pose[:, 4:7]], dim=1)   # az, el, th, d, px, py, score
-        if world > 1:
+        if world > 1 and gather:
             res = res.contiguous()
             if rehearsal:                                     # gloo gathers host tensors
                 part = [torch.empty(n, 7) for _ in range(world)]
@@ -266,56 +283,111 @@ def main():
     if rank == 0:
         host = res
         # accuracy of the run against the synthetic ground truth (sanity, rank 0's own images)
-        from nemo_amd.utils import pose_error
+        from nemo_amd.utils import camera_position_from_spherical_angles, pose_error
         errs = [pose_error(dict(azimuth=float(gts["azimuth"][i]), elevation=float(gts["elevation"][i]), theta=float(gts["theta"][i])),
                            dict(azimuth=float(host[i, 0]), elevation=float(host[i, 1]), theta=float(host[i, 2]))) for i in range(B)]
         med_err = sorted(errs)[len(errs) // 2] * 180 / math.pi
         n_hyp_steps = args.steps * B * world * EPOCHS * K_HYP
-        solve_ms = kern_ms["solve"]
-        achieved = G * B * K_HYP * EPOCHS * ALGO_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9
-        # HBM-side traffic of the same launch shape, from the committed rocprofv3 --pmc passes (bench.py cannot
-        # run the profiler on itself); None when the launch shape differs from the profiled one.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_solve_traffic_v4.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("hypotheses_per_launch") == G * B * K_HYP and tj.get("adam_steps") == EPOCHS:
-                traffic = (tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0
-        # the kernels in front of the solve are HBM-bound streams: algorithmic bytes of one launch over G*B images
-        n_img = G * B
+        n_img, n_hyp = G * B, G * B * K_HYP
         fm_bytes = C * H * W * 4
-        table_bytes = 4 * math.prod(ops.table_shape(mod.mesh, 1, H * W))
-        front = {
-            "similarity_table": n_img * (table_bytes + fm_bytes),                       # table written once, maps read once
-            "grid_score": -(-n_img // 256) * packed.data.numel() + 3 * n_img * fm_bytes,  # packed grid per 256 images; maps read, fragments written + read
-            "clutter_score": n_img * (fm_bytes + H * W * 4),
-        }
-        other = {k: {"bound": "hbm", "achieved": b / (kern_ms[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": b / (kern_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b}
-                 for k, b in front.items()}
+
+        # ---- what one solve launch has to move (un-timed census of one group on this GPU) ----
+        # per hypothesis-step: one 16-byte record per covered pixel (three table entries + the clutter score); per hypothesis:
+        # the table tiles it computes (written once, 4 KB each) and the feature columns of the pixel tiles they lie in (C x 32 x 4 B);
+        # once per launch: the vertex bank's matrix-core operand.  Covered pixels are counted at the final poses.
+        one = one_group(G, gather=False)                         # [n_img, 7] az, el, th, d, px, py, score
+        torch.cuda.synchronize()
+        loc = one[:n_img]
+        with torch.no_grad():
+            campos = camera_position_from_spherical_angles(loc[:, 3], loc[:, 1], loc[:, 0], device=dev)
+            covered = 0
+            for i0 in range(0, n_img, 64):
+                covered += int((mod(campos[i0:i0 + 64], loc[i0:i0 + 64, 2].contiguous()).abs().sum(dim=1) != 0).sum())
+        covered *= K_HYP                                         # every hypothesis of an image taken as its best one
+        tiles = pixel_tiles = None
+        solve_algo = EPOCHS * covered * 16
+        if not args.complete_table:
+            tables[0][:n_img].fill_(float("nan"))
+            one_group(G, gather=False)
+            torch.cuda.synchronize()
+            filled = ~torch.isnan(tables[0][:n_img])             # [n_img, HW/128, V/4, 128, 4]
+            tiles = int(filled.sum()) // 1024
+            pixel_tiles = int(filled.any(dim=4).any(dim=2).view(n_img, -1, 4, 32).any(dim=3).sum())
+            del filled
+            bank_bytes = -(-v.shape[0] // 32) * 32 * C * 2 * 2   # two f16 pieces per value
+            solve_algo += tiles * 4096 + pixel_tiles * C * 32 * 4 + bank_bytes
+        solve_ms = kern_ms["solve"]
+        achieved = solve_algo / (solve_ms * 1e-3) / 1e9
+
+        # ---- counters of the same launch shape from the committed rocprofv3 --pmc passes (bench.py cannot profile itself) ----
+        traffic = valu = grid_mfma_busy = None
+        cpath = os.path.join(ROOT, "profiles", "r2_solve_counters.json")
+        if os.path.exists(cpath):
+            with open(cpath) as fh:
+                cj = json.load(fh)
+            if (cj.get("hypotheses_per_launch") == n_hyp and cj.get("adam_steps") == EPOCHS
+                    and cj.get("on_demand_table") == (not args.complete_table)):
+                traffic = (cj["fetch_size_kb_per_launch"] + cj["write_size_kb_per_launch"]) * 1024.0
+                # vector issue: a SIMD issues one wave-instruction per 2 cycles (64 lanes over a 32-wide unit)
+                peak_issue = cj["compute_units"] * 4 * cj["shader_clock_ghz"] * 1e9 / 2
+                valu = {"wave_instructions_per_launch": cj["sq_insts_valu_per_launch"], "peak_per_sec": peak_issue,
+                        "frac": cj["sq_insts_valu_per_launch"] / (solve_ms * 1e-3) / peak_issue,
+                        "model": f"{cj['compute_units']} CUs x 4 SIMDs x {cj['shader_clock_ghz']} GHz / 2 cycles per wave-instruction",
+                        "source": "profiles/r2_solve_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+            if cj.get("grid_mfma", {}).get("images_per_launch") == n_img:
+                grid_mfma_busy = cj["grid_mfma"].get("mfma_busy_frac")
+
+        # ---- the kernels in front of the solve: algorithmic bytes / flops of one launch over n_img images ----
+        front = {"clutter_score": {"bound": "hbm", "algorithmic": n_img * (fm_bytes + H * W * 4)}}       # maps read, scores written
+        n_poses = int(pre.shape[0])
+        # grid scoring: 2 B N C HW useful flops (the matrix cores execute three f16 piece products for each)
+        front["grid_score"] = {"bound": "mfma", "algorithmic": 2.0 * n_img * n_poses * C * H * W}
+        if args.complete_table:
+            table_bytes = 4 * math.prod(ops.table_shape(mod.mesh, 1, H * W))
+            front["similarity_table"] = {"bound": "hbm", "algorithmic": n_img * (table_bytes + fm_bytes)}   # table written once, maps read once
+        other = {}
+        for k, d in front.items():
+            rate = d["algorithmic"] / (kern_ms[k] * 1e-3)
+            if d["bound"] == "hbm":
+                other[k] = {"bound": "hbm", "achieved": rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / 1e9 / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_launch": d["algorithmic"]}
+            else:
+                other[k] = {"bound": "mfma", "achieved": rate / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": rate / 1e12 / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_launch": d["algorithmic"],
+                            "matrix_pipe_busy_frac_of_grid_mfma_kernel": grid_mfma_busy,
+                            "note": "useful flops 2 B N C HW; the two-piece f16 operands cost three matrix-core products per useful one, and the "
+                                    "launch time includes the re-layout of the feature maps into operand fragments"}
+        hx, hy, hz = HALF_EXTENTS
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "images_per_sec": args.steps * B * world / elapsed,
-            "config": {"workload": "omni_nemo_pose_3d car (BASELINE configs[1]): batch 64 synthetic 640x800 images per GPU, "
-                                   "80x100x128 feature maps, cuboid mesh V=1118 F=1904, 144-pose pre-rendered grid scoring + "
-                                   "300 Adam steps per image, random-init vertex bank",
-                       "batch_per_gpu": B, "global_batch": B * world, "grid_poses": int(pre.shape[0]), "adam_steps": EPOCHS,
-                       "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger, "similarity_table": "complete, in front of the solve" if args.complete_table else "tiles on demand inside the solve",
+            "config": {"workload": (f"multi-hypothesis solve (BASELINE configs[2]): {STRONG_TOTAL_IMAGES} synthetic 640x800 images x "
+                                    f"{STRONG_HYPOTHESES} initial poses in total, sharded over the GPUs, " if args.strong else
+                                    "omni_nemo_pose_3d car (BASELINE configs[1]): batch 64 synthetic 640x800 images per GPU, ") +
+                                   f"80x100x128 feature maps, cuboid mesh V={v.shape[0]} F={f.shape[0]} with half extents {hx}/{hy}/{hz} (half of a "
+                                   "car's, so that it fits the 100-pixel map at distance 5), 144-pose pre-rendered grid scoring + "
+                                   "300 Adam steps per hypothesis, random-init vertex bank",
+                       "batch_per_gpu": B, "global_batch": B * world, "grid_poses": n_poses, "adam_steps": EPOCHS,
+                       "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger,
+                       "similarity_table": "complete, in front of the solve" if args.complete_table else "tiles on demand inside the solve",
                        "hypotheses_per_image": K_HYP,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
-            "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": G * B * K_HYP,
+            "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": n_hyp,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
             "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": G * B * K_HYP * EPOCHS * ALGO_BYTES_PER_HYP_STEP,
-                         "traffic_source": "profiles/r1_solve_traffic_v4.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
-                         "note": "achieved = 300 steps x hypotheses per launch x 4.128 MB (one read of the image's feature map + clutter "
-                                 "map per hypothesis-step, the streaming design's algorithmic bytes) / measured launch time; the "
-                                 "kernel reads a precomputed vertex x pixel similarity table instead (3 floats per covered pixel), "
-                                 "so frac > 1 means it beats the streaming roofline"},
+                         "algorithmic_bytes_per_launch": solve_algo,
+                         "census": {"covered_pixels_per_step": covered, "table_tiles_computed": tiles, "pixel_tiles_touched": pixel_tiles,
+                                    "table_fraction_computed": None if tiles is None else tiles * 1024 / (n_img * math.prod(ops.table_shape(mod.mesh, 1, H * W)))},
+                         "traffic_source": "profiles/r2_solve_counters.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
+                         "valu_issue": valu,
+                         "note": "algorithmic bytes of the implemented design: 300 steps x covered pixels x 16 B (three table entries + clutter "
+                                 "score per covered pixel) + computed table tiles x 4 KB + touched pixel tiles x 16 KB of feature map + the "
+                                 "bank operand, / measured launch time.  The kernel is bound by vector issue and LDS latency, not by HBM: "
+                                 "see valu_issue"},
+            "speedup_vs_streaming_design": n_hyp * EPOCHS * STREAM_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "front_kernel_rooflines": other,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
