@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help=f"BASELINE configs[2]: {STRONG_TOTAL_IMAGES} images x {STRONG_HYPOTHESES} hypotheses in total, sharded over the ranks "
                          "(strong scaling: a step is one pass over all of them); overrides --batch, --hypotheses and --in-flight")
+    ap.add_argument("--separate-clutter", action="store_true",
+                    help="clutter score and grid scoring as two calls (nemo_clutter_score + nemo_grid_score_packed) instead of one read of "
+                         "the feature maps for both (nemo_clutter_grid_score_packed, the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true",
                     help="let the groups on different launch streams start together (default: a group's clutter / grid / table "
@@ -180,7 +183,8 @@ def main():
     tables = [ops.workspace_tables(mod.mesh, w_, G * B, H * W) for w_ in work]
     gathered = [[torch.empty(G * B, 7, device=dev) for _ in range(world)] for _ in range(n_streams)] if world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}
+    kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}   # fused: all of the first two under grid_score
+    grid_ws = [torch.empty(ops.grid_score_workspace_bytes(packed, G * B), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
 
     # Staggered groups: the front kernels (clutter, grid, table: HBM / matrix-core bound) of group k+1 wait for the
     # front kernels of group k, so they run beside solve(k) (vector-issue / latency bound) instead of beside front(k).
@@ -197,10 +201,15 @@ def main():
             torch.cuda.current_stream().wait_event(front_ev[0])
         if timed:
             ev[0].record()
-        clu = ops.clutter_score(x, clutter)
-        if timed:
-            ev[1].record()
-        loss, idx, _ = ops.grid_score(pre, x, clu, packed=packed)
+        if args.separate_clutter:
+            clu = ops.clutter_score(x, clutter)
+            if timed:
+                ev[1].record()
+            loss, idx, _ = ops.grid_score(pre, x, clu, packed=packed)
+        else:
+            if timed:
+                ev[1].record()
+            clu, loss, idx, _ = ops.clutter_and_grid_score(x, clutter, packed, workspace=grid_ws[slot])
         h2i = None
         if K_HYP > 1:       # the K best grid poses of every image, best first (as solve_pose(..., hypotheses=K))
             idx = torch.sort(loss, dim=1, stable=True)[1][:, :K_HYP].reshape(-1)
@@ -338,7 +347,9 @@ def main():
                 grid_mfma_busy = cj["grid_mfma"].get("mfma_busy_frac")
 
         # ---- the kernels in front of the solve: algorithmic bytes / flops of one launch over n_img images ----
-        front = {"clutter_score": {"bound": "hbm", "algorithmic": n_img * (fm_bytes + H * W * 4)}}       # maps read, scores written
+        front = {}
+        if args.separate_clutter:
+            front["clutter_score"] = {"bound": "hbm", "algorithmic": n_img * (fm_bytes + H * W * 4)}     # maps read, scores written
         n_poses = int(pre.shape[0])
         # grid scoring: 2 B N C HW useful flops (the matrix cores execute three f16 piece products for each)
         front["grid_score"] = {"bound": "mfma", "algorithmic": 2.0 * n_img * n_poses * C * H * W}
@@ -372,6 +383,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": n_poses, "adam_steps": EPOCHS,
                        "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger,
                        "similarity_table": "complete, in front of the solve" if args.complete_table else "tiles on demand inside the solve",
+                       "clutter_score": "its own pass over the feature maps" if args.separate_clutter else "scored by the pass that builds the grid scoring's operand fragments (timed under grid_score)",
                        "hypotheses_per_image": K_HYP,
                        "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": n_hyp,

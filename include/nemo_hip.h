@@ -171,6 +171,16 @@ int nemo_grid_score_packed(const void* packed, const float* feat, const float* c
                            int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* nemo_clutter_score followed by nemo_grid_score_packed with that clutter score, from ONE read of the feature maps
+ * (batch_solve_pose.py:214-225 and :128-164 both read the whole batch): the pass that turns the maps into
+ * matrix-core operand fragments also scores the clutter vectors.  clutter [K,C]; out_clutter_score [B,HW] is written
+ * (bit for bit what nemo_clutter_score gives) and used; the other outputs and the workspace
+ * (nemo_grid_score_packed_workspace bytes) as nemo_grid_score_packed.  More than 4 clutter vectors: the two steps
+ * run one after the other inside the call. */
+int nemo_clutter_grid_score_packed(const void* packed, const float* feat, const float* clutter, int32_t K, int32_t N, int32_t B,
+                                   int32_t C, int32_t HW, float* out_clutter_score, float* out_loss, int32_t* out_argmin,
+                                   float* out_min, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Scoring of re-centred copies of a batch, the 6-D initialisation loop of batch_solve_pose.py:264-295 (every
  * principal-point sample re-centres the whole batch with align_no_centered, :65-90, and scores it against the
  * grid): virtual image bv is source image bv % B_src resampled with (dist_src, dist_tgt, p_src, p_tgt)[bv] as

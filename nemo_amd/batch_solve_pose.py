@@ -47,7 +47,7 @@ def get_pre_render_samples(inter_module, azum_samples, elev_samples, theta_sampl
 
 
 def get_init_pos_rendered_dim0(samples_maps, samples_pos, samples_theta, predicted_maps, clutter_scores=None,
-                               batch_size=32, top_k=1):
+                               batch_size=32, top_k=1, grid_scores=None):
     """(init campos [b,3], init theta [b], min loss [b]) - arg-min of the grid loss per image.
     `batch_size` (the reference's chunk size) is accepted and ignored: nothing is chunked.
     With top_k > 1 the k lowest-loss grid poses of every image come back instead, best first:
@@ -117,10 +117,12 @@ def _clutter_rows(clutter_bank, c):
 
 
 def initial_poses(feature_map, clutter_score, cameras, cam_pos_pre_rendered, theta_pre_rendered, feature_pre_rendered,
-                  principal=None, pre_render=True, dof=3, n_hyp=1, inter_module=None, distance_source=None, distance_target=None):
+                  principal=None, pre_render=True, dof=3, n_hyp=1, inter_module=None, distance_source=None, distance_target=None,
+                  grid_scores=None):
     """Step 2 of solve_pose (reference batch_solve_pose.py:233-301): pose-grid scoring and the choice of the starting
     pose(s) of every image.  -> (init_C [b * n_hyp, 3], init_theta [b * n_hyp], init_principal [b * n_hyp, 2] or None),
-    hypothesis-major (rows i * n_hyp + k), best first."""
+    hypothesis-major (rows i * n_hyp + k), best first.  grid_scores: the grid losses of the batch as it is (no
+    re-centring) when the caller has computed them with the clutter score (see solve_pose)."""
     b = feature_map.shape[0]
     dev = feature_map.device
     size = cameras.image_size                    # [1, 2] = (H, W)
@@ -140,7 +142,7 @@ def initial_poses(feature_map, clutter_score, cameras, cam_pos_pre_rendered, the
         if pre_render:
             init_C, init_theta, _ = get_init_pos_rendered_dim0(feature_pre_rendered, cam_pos_pre_rendered,
                                                                theta_pre_rendered, t_feature_map, t_clutter_score,
-                                                               top_k=n_hyp)
+                                                               top_k=n_hyp, grid_scores=grid_scores if principal is None else None)
             if n_hyp > 1:                        # [b, K, ...] -> hypothesis-major rows i * K + k
                 init_C, init_theta = init_C.reshape(b * n_hyp, 3), init_theta.reshape(b * n_hyp)
                 if init_principal is not None:
@@ -242,9 +244,16 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     if n_hyp > 1 and dof != 6 and not pre_render:
         raise NotImplementedError("hypotheses > 1 needs the pre-rendered grid")
 
-    # Step 1: clutter score
+    # Step 1: clutter score.  When step 2 scores the batch as it is against a packed grid, both steps come from one
+    # read of the feature maps (the grid losses are then ready before step 2 is timed).
     t0 = time.time()
-    clutter_score = ops.clutter_score(feature_map, _clutter_rows(clutter_bank, c))
+    packed = getattr(feature_pre_rendered, "_nemo_packed_grid", None) if pre_render else None
+    grid_scores = None
+    if packed is not None and dof in (3, 4) and principal is None:
+        clutter_score, g_loss, g_idx, g_min = ops.clutter_and_grid_score(feature_map, _clutter_rows(clutter_bank, c), packed)
+        grid_scores = (g_loss, g_idx, g_min)
+    else:
+        clutter_score = ops.clutter_score(feature_map, _clutter_rows(clutter_bank, c))
     t1 = time.time()
     pred["pre_compute_time"] = t1 - t0
 
@@ -256,7 +265,7 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     init_C, init_theta, init_principal = initial_poses(
         feature_map, clutter_score, inter_module.rasterizer.cameras, cam_pos_pre_rendered, theta_pre_rendered,
         feature_pre_rendered, principal=principal, pre_render=pre_render, dof=dof, n_hyp=n_hyp, inter_module=inter_module,
-        distance_source=ds_kw, distance_target=dt_kw)
+        distance_source=ds_kw, distance_target=dt_kw, grid_scores=grid_scores)
     t2 = time.time()
     pred["pre_rendering_time"] = t2 - t1
 

@@ -98,6 +98,86 @@ __global__ __launch_bounds__(256) void grid_feat_kernel(const float* __restrict_
     }
 }
 
+// The same pass also scoring the clutter vectors (batch_solve_pose.py:214-225: 1x1 convolution with the K clutter
+// vectors, max over K): the feature maps are read once for both.  One workgroup per (32 pixels, column block) walks
+// the k-steps; thread t keeps the running dot products of image t / 8 at pixels t % 8 + 8 j, channels in ascending
+// order with one fused multiply-add each, i.e. the very sums of clutter_kernel.
+template <int K>
+__global__ __launch_bounds__(256) void grid_feat_clutter_kernel(const float* __restrict__ feat, const float* __restrict__ clutter,
+                                                                uint4* __restrict__ featp, float* __restrict__ out_clu, int B, int C,
+                                                                int HW, int ncb) {
+    __shared__ float brick[32 * GF_IMG_STRIDE];
+    __shared__ float cl[K * 128];
+    const int nks = C / 16;
+    const int p0 = blockIdx.x * GF_PX, cb = blockIdx.y;
+    const int px = threadIdx.x & 31;
+    const int p = p0 + px;
+    const int pc = p < HW ? p : HW - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cimg = threadIdx.x >> 3, cpx = threadIdx.x & 7;
+    for (int i = threadIdx.x; i < K * C; i += 256) cl[i] = clutter[i];
+    float acc[4][K];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[j][k] = 0.0f;
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll 1
+        for (int r0 = threadIdx.x >> 5; r0 < 32 * 16; r0 += 8 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + 8 * u, img = r >> 4, ch = r & 15;
+                const int b = min(cb * 32 + img, B - 1);
+                v[u] = feat[((size_t)b * C + ks * 16 + ch) * HW + pc];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + 8 * u, img = r >> 4, ch = r & 15;
+                brick[img * GF_IMG_STRIDE + ch * (GF_PX + 1) + px] = (cb * 32 + img < B && p < HW) ? v[u] : 0.0f;
+            }
+        }
+        __syncthreads();
+        {
+            const int img = lane & 31, kq = lane >> 5;
+            for (int q = wave; q < GF_PX; q += 4) {
+                const int pq = p0 + q;
+                if (pq >= HW) break;
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = scale_clamp(brick[img * GF_IMG_STRIDE + (8 * kq + j) * (GF_PX + 1) + q]);
+                uint4 pcs[SG_NP];
+                split8(x, pcs);
+                const size_t base = (((size_t)pq * ncb + cb) * nks + ks) * 2;
+                featp[(base + 0) * 64 + lane] = pcs[0];
+                featp[(base + 1) * 64 + lane] = pcs[1];
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f = brick[cimg * GF_IMG_STRIDE + ch * (GF_PX + 1) + cpx + 8 * j];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[j][k] = __builtin_fmaf(f, cl[k * C + ks * 16 + ch], acc[j][k]);
+            }
+        }
+        __syncthreads();
+    }
+    const int b = cb * 32 + cimg;
+    if (b < B) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pj = p0 + cpx + 8 * j;
+            float best = acc[j][0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) best = fmaxf(best, acc[j][k]);
+            if (pj < HW) out_clu[(size_t)b * HW + pj] = best;
+        }
+    }
+}
+
 // The same for re-centred copies of a batch (6-D initialisation, batch_solve_pose.py:264-295): virtual image
 // bv is source image bv % Bsrc resampled with its own re-centring parameters (resample.h).  The resampled maps
 // are never written: the four taps of a (virtual image, pixel) are worked out once per brick row group and
@@ -286,6 +366,36 @@ static void launch_mfma_nks(const void* packed, const void* featp, const float* 
             default: launch_mfma_slice<NKS, 9>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
         }
     }
+}
+
+constexpr int kFusedClutterMax = 4;         // clutter vectors the fused fragment + clutter pass takes
+
+template <int NKS>
+static void launch_mfma_nks(const void* packed, const void* featp, const float* clu, int N, int B, int HW, float* partial, hipStream_t st);
+
+// Clutter scores [B, HW] of K <= kFusedClutterMax clutter vectors and the pose-grid losses from one read of the maps.
+// Returns 1 when the shape is not one the fused pass takes (the caller then runs the two steps one after the other).
+int launch_grid_mfma_clutter(const void* packed, const float* feat, const float* clutter, int K, int N, int B, int C, int HW,
+                             float* out_clu, void* featp, float* partial, hipStream_t st) {
+    const int ncb = (B + 31) / 32;
+    if (K < 1 || K > kFusedClutterMax || C > 128) return 1;
+    if (ncb > 65535) return -1;
+    const dim3 grid((HW + GF_PX - 1) / GF_PX, ncb);
+    uint4* fp = (uint4*)featp;
+    switch (K) {
+        case 1: hipLaunchKernelGGL(grid_feat_clutter_kernel<1>, grid, dim3(256), 0, st, feat, clutter, fp, out_clu, B, C, HW, ncb); break;
+        case 2: hipLaunchKernelGGL(grid_feat_clutter_kernel<2>, grid, dim3(256), 0, st, feat, clutter, fp, out_clu, B, C, HW, ncb); break;
+        case 3: hipLaunchKernelGGL(grid_feat_clutter_kernel<3>, grid, dim3(256), 0, st, feat, clutter, fp, out_clu, B, C, HW, ncb); break;
+        default: hipLaunchKernelGGL(grid_feat_clutter_kernel<4>, grid, dim3(256), 0, st, feat, clutter, fp, out_clu, B, C, HW, ncb); break;
+    }
+    switch (C / 16) {
+        case 1: launch_mfma_nks<1>(packed, featp, out_clu, N, B, HW, partial, st); break;
+        case 2: launch_mfma_nks<2>(packed, featp, out_clu, N, B, HW, partial, st); break;
+        case 4: launch_mfma_nks<4>(packed, featp, out_clu, N, B, HW, partial, st); break;
+        case 8: launch_mfma_nks<8>(packed, featp, out_clu, N, B, HW, partial, st); break;
+        default: return -2;
+    }
+    return 0;
 }
 
 // featp: grid_feat_bytes(B, C, HW) bytes of scratch; partial: grid_chunks(HW) * B * N floats.

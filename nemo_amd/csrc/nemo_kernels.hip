@@ -843,6 +843,8 @@ size_t grid_feat_bytes(int B, int C, int HW);
 int launch_grid_pack(const float* pre, void* packed, int N, int C, int HW, hipStream_t st);
 int launch_grid_mfma(const void* packed, const float* feat, const float* clu, int N, int B, int C, int HW, void* featp,
                      float* partial, hipStream_t st);
+int launch_grid_mfma_clutter(const void* packed, const float* feat, const float* clutter, int K, int N, int B, int C, int HW,
+                             float* out_clu, void* featp, float* partial, hipStream_t st);
 }
 
 extern "C" size_t nemo_grid_pack_bytes(int32_t N, int32_t C, int32_t HW) {
@@ -884,6 +886,34 @@ extern "C" int nemo_grid_score_packed(const void* packed, const float* feat, con
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)partial, clu, N, B, HW, nemo::grid_chunks(HW),
                        out_loss, out_argmin, out_min);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" int nemo_clutter_grid_score_packed(const void* packed, const float* feat, const float* clutter, int32_t K, int32_t N, int32_t B,
+                                              int32_t C, int32_t HW, float* out_clutter_score, float* out_loss, int32_t* out_argmin,
+                                              float* out_min, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!packed || !feat || !clutter || !out_clutter_score || !out_argmin || K <= 0 || N <= 0 || B < 0 || C <= 0 || HW <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_clutter_grid_score_packed: bad argument");
+    if (!nemo::grid_mfma_supported(C))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_clutter_grid_score_packed: %d channels (takes 16, 32, 64 or 128)", C);
+    const size_t need = nemo_grid_score_packed_workspace(N, B, C, HW);
+    if (!workspace || workspace_bytes < need)
+        return fail(NEMO_ERR_INVALID, "nemo_clutter_grid_score_packed: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)((char*)workspace + align256(nemo::grid_feat_bytes(B, C, HW)));
+    const int rc = nemo::launch_grid_mfma_clutter(packed, feat, clutter, K, N, B, C, HW, out_clutter_score, workspace, partial, st);
+    if (rc < 0) return fail(NEMO_ERR_UNSUPPORTED, "nemo_clutter_grid_score_packed: batch too large for one launch");
+    if (rc > 0) {       // more clutter vectors than the fused pass takes: the two steps one after the other
+        const int r1 = nemo_clutter_score(feat, clutter, B, C, HW, K, out_clutter_score, stream);
+        if (r1) return r1;
+        return nemo_grid_score_packed(packed, feat, out_clutter_score, N, B, C, HW, out_loss, out_argmin, out_min, workspace,
+                                      workspace_bytes, stream);
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)partial, (const float*)out_clutter_score, N, B, HW,
+                       nemo::grid_chunks(HW), out_loss, out_argmin, out_min);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

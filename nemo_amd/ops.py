@@ -262,6 +262,39 @@ def grid_score(pre_rendered, feature_map, clutter_score_map=None, packed=None):
     return loss, amin, mn
 
 
+def clutter_and_grid_score(feature_map, clutter, packed, workspace=None):
+    """clutter_score followed by grid_score(..., packed=packed) from one read of the feature maps.
+    feature_map [B,C,H,W], clutter [K,C], packed = grid_pack of the pose grid
+    -> (clutter_score [B,H,W], loss [B,N], argmin [B] int32, min_loss [B]), each bit for bit what the two calls give.
+    workspace: optional uint8 tensor of grid_score_workspace_bytes(packed, B) bytes kept by the caller."""
+    lib = _lib.load()
+    fm = f32c(feature_map)
+    B = fm.shape[0]
+    N, Cc, H, W = packed.shape
+    if tuple(fm.shape[1:]) != (Cc, H, W):
+        raise ValueError(f"feature_map {tuple(fm.shape)} does not match the packed grid {packed.shape}")
+    cl = f32c(clutter).reshape(-1, Cc)
+    clu = torch.empty(B, H, W, device=fm.device)
+    loss = torch.empty(B, N, device=fm.device)
+    amin = torch.empty(B, dtype=torch.int32, device=fm.device)
+    mn = torch.empty(B, device=fm.device)
+    nbytes = lib.nemo_grid_score_packed_workspace(N, B, Cc, H * W)
+    ws = workspace if workspace is not None else torch.empty(max(nbytes, 1), dtype=torch.uint8, device=fm.device)
+    if ws.dtype != torch.uint8 or ws.numel() < nbytes or ws.device != fm.device:
+        raise ValueError(f"workspace must be a uint8 tensor of at least {nbytes} bytes on {fm.device}")
+    with torch.cuda.device(fm.device):
+        check(lib.nemo_clutter_grid_score_packed(ptr(packed.data, torch.uint8), ptr(fm), ptr(cl), cl.shape[0], N, B, Cc, H * W, ptr(clu),
+                                                 ptr(loss), ptr(amin, torch.int32), ptr(mn), ptr(ws, torch.uint8), ws.numel(),
+                                                 stream_ptr()), "nemo_clutter_grid_score_packed")
+    return clu, loss, amin, mn
+
+
+def grid_score_workspace_bytes(packed, B):
+    """Bytes of the workspace grid_score / clutter_and_grid_score need for B images against a packed grid."""
+    N, Cc, H, W = packed.shape
+    return int(_lib.load().nemo_grid_score_packed_workspace(N, B, Cc, H * W))
+
+
 def grid_score_static(pre_rendered, feature_map, clutter_score_map, out_loss, out_argmin, out_min):
     """grid_score through the entry point that allocates nothing: the caller brings every tensor (inputs float32
     contiguous on the device, out_loss [B,N] f32, out_argmin [B] i32, out_min [B] f32) and the library keeps the

@@ -232,6 +232,36 @@ def test_grid_score_small(small):
     assert rel_err(loss2, 1 - obj.mean(dim=(2, 3))) < REL
 
 
+@pytest.mark.parametrize("which,n_img,n_clutter", [("small", 37, 1), ("small", 5, 3), ("full", 33, 1), ("small", 4, 6)])
+def test_clutter_and_grid_score_in_one_pass(which, n_img, n_clutter, request):
+    """nemo_clutter_grid_score_packed (one read of the feature maps for the clutter score and the grid scoring's operand
+    fragments): clutter score, grid losses, arg-min and minimum equal, bit for bit, what nemo_clutter_score followed
+    by nemo_grid_score_packed gives - ragged image counts, several clutter vectors, and more of them than the fused
+    pass takes (the call then runs the two steps itself)."""
+    import nemo_amd
+    from nemo_amd import ops
+    sc = request.getfixturevalue(which)
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, _, _ = nemo_amd.get_pre_render_samples(sc.mod, az[::3], el, th, di)
+    packed = ops.grid_pack(maps.squeeze(1))
+    fm, _ = sc.feature_maps(n_img)
+    fm = fm.to(sc.device)
+    g = torch.Generator().manual_seed(40 + n_clutter)
+    bank = torch.cat([sc.clutter, torch.nn.functional.normalize(torch.randn(n_clutter - 1, sc.C, generator=g), dim=1)]).to(sc.device)
+    clu = ops.clutter_score(fm, bank)
+    loss, amin, mn = ops.grid_score(None, fm, clu, packed=packed)
+    clu2, loss2, amin2, mn2 = ops.clutter_and_grid_score(fm, bank, packed)
+    assert torch.equal(clu2, clu)
+    assert torch.equal(loss2, loss) and torch.equal(amin2, amin) and torch.equal(mn2, mn)
+    # a caller-kept workspace, reused: same answers
+    ws = torch.empty(ops.grid_score_workspace_bytes(packed, n_img), dtype=torch.uint8, device=sc.device)
+    for _ in range(2):
+        clu3, loss3, amin3, _ = ops.clutter_and_grid_score(fm, bank, packed, workspace=ws)
+        assert torch.equal(clu3, clu) and torch.equal(loss3, loss) and torch.equal(amin3, amin)
+    with pytest.raises(ValueError):
+        ops.clutter_and_grid_score(fm, bank, packed, workspace=ws[:16])
+
+
 def test_render_backward_matches_autograd(small):
     sc = small
     fm, _ = sc.feature_maps(3)
