@@ -984,8 +984,9 @@ __device__ inline void table_tiles_nks(const float* __restrict__ col, size_t HW,
 
 // The tiles (vertex block vb_first + v, pixel tile pt32) for every bit v set in vbmask (words in LDS).  A function of
 // its own (not inlined): its registers (the image's operand, the accumulators) are then not part of the optimisation
-// loop's allocation, which has none to spare; it is called off the loop's common path.
-__device__ __attribute__((noinline)) void table_tiles(const float* feat, const uint4* bank, float* table, int HW, int nks, int vg_n,
+// loop's allocation, which has none to spare; it is called off the loop's common path, and marked cold so that what
+// the loop must save around the call is saved on that path and not reloaded in every phase of every step.
+__device__ __attribute__((noinline, cold)) void table_tiles(const float* feat, const uint4* bank, float* table, int HW, int nks, int vg_n,
                                                       size_t apiece, float unscale, int vb_first, int nvb, int pt32,
                                                       const unsigned int* vbmask) {
     const int lane = threadIdx.x & 63, lk = lane >> 5, px = lane & 31;
@@ -1099,7 +1100,7 @@ __device__ inline void ensure_table_tiles_call(lds_u32* zkey, lds_u32* present, 
             code[u] = absent ? (pt << 16 | fb) : kNone;
             miss |= absent;
         }
-        if (!__any(miss)) continue;
+        if (__builtin_expect(!__any(miss), 1)) continue;
         for (;;) {                                   // rare: one round per pixel tile with something missing
             unsigned int mine = kNone;
 #pragma unroll
