@@ -367,7 +367,8 @@ def main():
                             "frac": rate / 1e12 / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_launch": d["algorithmic"],
                             "matrix_pipe_busy_frac_of_grid_mfma_kernel": grid_mfma_busy,
                             "note": "useful flops 2 B N C HW; the two-piece f16 operands cost three matrix-core products per useful one, and the "
-                                    "launch time includes the re-layout of the feature maps into operand fragments"}
+                                    "time includes the pass that turns the feature maps into operand fragments (and, unless --separate-clutter, "
+                                    "scores the clutter vectors) and the finalize pass"}
         hx, hy, hz = HALF_EXTENTS
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
