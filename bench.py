@@ -153,7 +153,10 @@ def main():
     dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count() if rehearsal else local_rank}")
     torch.cuda.set_device(dev)
     import torch.distributed as dist
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created even for a single rank, so that the gather
+    # of the results takes the RCCL path whatever the number of ranks
+    grouped = world > 1 or "RANK" in os.environ
+    if grouped:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -187,7 +190,7 @@ def main():
     # per launch stream: room for the similarity tables (complete, or the tiles the solve computes for itself) + feature fragments
     work = [torch.empty(ops.solve_workspace_bytes(mod.mesh, G * B, H * W), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
     tables = [ops.workspace_tables(mod.mesh, w_, G * B, H * W) for w_ in work]
-    gathered = [[torch.empty(G * B, 7, device=dev) for _ in range(world)] for _ in range(n_streams)] if world > 1 else None
+    gathered = [[torch.empty(G * B, 7, device=dev) for _ in range(world)] for _ in range(n_streams)] if grouped else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}   # fused: all of the first two under grid_score
     grid_ws = [torch.empty(ops.grid_score_workspace_bytes(packed, G * B), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
@@ -242,7 +245,7 @@ def main():
             pose = pose[torch.arange(n, device=dev), pose[:, :, 6].argmin(dim=1)]
         sph = ops.spherical_angles(pose[:, 0:3])
         res = torch.cat([sph[:, 2:3], sph[:, 1:2], pose[:, 3:4], sph[:, 0:1], pose[:, 4:7]], dim=1)   # az, el, th, d, px, py, score
-        if world > 1 and gather:
+        if grouped and gather:
             res = res.contiguous()
             if rehearsal:                                     # gloo gathers host tensors
                 part = [torch.empty(n, 7) for _ in range(world)]
@@ -260,7 +263,7 @@ def main():
         return res
 
     def sync():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -290,7 +293,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     res = host_res[0][:B]
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
@@ -392,7 +395,8 @@ def main():
                        "similarity_table": "complete, in front of the solve" if args.complete_table else "tiles on demand inside the solve",
                        "clutter_score": "its own pass over the feature maps" if args.separate_clutter else "scored by the pass that builds the grid scoring's operand fragments (timed under grid_score)",
                        "hypotheses_per_image": K_HYP,
-                       "partition": f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU"},
+                       "partition": (f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU") +
+                                    (" (process group: " + dist.get_backend() + ")" if grouped else "")},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": n_hyp,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
             "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -412,7 +416,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(mod, mem, clutter, v, f, fm_g[0], pre, cs, ths)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
