@@ -105,9 +105,10 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default 256 (8 with --strong)")
     ap.add_argument("--warmup", type=int, default=None, help="default 16 (1 with --strong)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 2: 64)")
-    ap.add_argument("--in-flight", type=int, default=8,
-                    help="batches processed together (a 64-image solve launch occupies an eighth of the chip; eight batches "
-                         "in flight fill the chip); every batch keeps its own loss normaliser")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="batches processed together: their kernels are launched once over all their images (a 64-image solve launch "
+                         "occupies an eighth of the chip, and the hardware refills compute units best inside one large launch); every "
+                         "batch keeps its own loss normaliser. Default: all of them in one launch up to 32 steps, 16 beyond")
     ap.add_argument("--hypotheses", type=int, default=1,
                     help="initial poses per image (the K best grid poses; BASELINE configs[2] uses 8); 1 = configs[1]")
     ap.add_argument("--streams", type=int, default=2, help="launch streams the groups alternate over")
@@ -132,6 +133,8 @@ def main():
         args.steps = 8 if args.strong else 256
     if args.warmup is None:
         args.warmup = 1 if args.strong else 16
+    if args.in_flight is None:
+        args.in_flight = args.steps if args.steps <= 32 else 16
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,7 +188,7 @@ def main():
     # compute units that the workgroups of a solve launch leave as they finish at different times.
     K_HYP = max(1, args.hypotheses)
     hyp_image = torch.arange(G * B, device=dev, dtype=torch.int32).repeat_interleave(K_HYP)
-    n_streams = max(1, args.streams)
+    n_streams = max(1, min(args.streams, -(-args.steps // G)))      # no more streams (and sets of buffers) than groups
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     # per launch stream: room for the similarity tables (complete, or the tiles the solve computes for itself) + feature fragments
     work = [torch.empty(ops.solve_workspace_bytes(mod.mesh, G * B, H * W), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
@@ -195,19 +198,18 @@ def main():
     kern_ms = {"clutter_score": 0.0, "grid_score": 0.0, "similarity_table": 0.0, "solve": 0.0}   # fused: all of the first two under grid_score
     grid_ws = [torch.empty(ops.grid_score_workspace_bytes(packed, G * B), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
 
-    # Staggered groups: the front kernels (clutter, grid, table: HBM / matrix-core bound) of group k+1 wait for the
-    # front kernels of group k, so they run beside solve(k) (vector-issue / latency bound) instead of beside front(k).
+    # Staggered groups: the front kernels (clutter + grid scoring, complete table: HBM / matrix-core bound) of group k+1 wait
+    # for the front kernels of group k, so they run beside solve(k) (vector-issue / latency bound) instead of beside front(k).
+    # (Measured and dropped: one stream for all front kernels and one of higher priority for all solves. The front kernels
+    # then run ahead into the middle of a solve launch, both slow down: 35 k images/s against 50 k.)
     front_ev = [None]
     stagger = not args.no_stagger and n_streams > 1
 
-    def one_group(g, timed=False, host_out=None, slot=0, gather=True):
-        """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major).
-        slot: which stream's buffers to use (the caller has made that stream current)."""
-        n = g * B
-        table = tables[slot]
+    trace = [] if os.environ.get("NEMO_BENCH_TRACE") == "1" else None     # diagnostic: per-group events of the timed region
+
+    def front_part(n, slot, timed):
+        """clutter score, grid scoring and the choice of the starting pose(s); the complete table if asked for."""
         x = fm_g[:n]
-        if stagger and front_ev[0] is not None:
-            torch.cuda.current_stream().wait_event(front_ev[0])
         if timed:
             ev[0].record()
         if args.separate_clutter:
@@ -226,13 +228,12 @@ def main():
         idx = idx.long()
         if timed:
             ev[2].record()
-        if args.complete_table:
-            tab = ops.similarity_table(mod.mesh, x, out=table[:n])
-        if stagger:
-            front_ev[0] = torch.cuda.Event()
-            front_ev[0].record()
-        if timed:
-            ev[3].record()
+        tab = ops.similarity_table(mod.mesh, x, out=tables[slot][:n]) if args.complete_table else None
+        return x, clu, idx, h2i, tab
+
+    def solve_part(g, n, fr, slot, timed, host_out, gather):
+        """300 Adam steps per hypothesis, read-out, gather over the ranks, copy to the host."""
+        x, clu, idx, h2i, tab = fr
         skw = dict(global_batch=B * world, dof=3, steps=EPOCHS, lr=0.05, betas=(0.4, 0.6), lr_gamma=0.2, lr_every=EPOCHS // 3)
         if args.complete_table:
             pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], hyp_to_image=h2i, **skw)
@@ -240,6 +241,10 @@ def main():
             pose, _ = ops.solve_from_features(mod.mesh, cam, x, clu, cs[idx], ths[idx], hyp_to_image=h2i, workspace=work[slot], **skw)
         if timed:
             ev[4].record()
+        done = None
+        if trace is not None and host_out is not None:
+            done = torch.cuda.Event(enable_timing=True)
+            done.record()
         if K_HYP > 1:       # keep the best-scoring hypothesis of every image
             pose = pose.view(n, K_HYP, 8)
             pose = pose[torch.arange(n, device=dev), pose[:, :, 6].argmin(dim=1)]
@@ -260,6 +265,29 @@ def main():
                 res = torch.cat(part)
         if host_out is not None:                    # the results go to (pinned) host memory per group
             host_out.copy_(res, non_blocking=True)
+        return res, done
+
+    def one_group(g, timed=False, host_out=None, slot=0, gather=True):
+        """g batches (g <= G) through the whole path; returns [world * g * B, 7] (rank-major).
+        slot: which stream's buffers to use (the caller has made that stream current)."""
+        n = g * B
+        tracing = trace is not None and host_out is not None
+        tr = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if tracing else None
+        if stagger and front_ev[0] is not None:
+            torch.cuda.current_stream().wait_event(front_ev[0])
+        if tracing:
+            tr[0].record()
+        fr = front_part(n, slot, timed)
+        if stagger:
+            front_ev[0] = torch.cuda.Event()
+            front_ev[0].record()
+        if tracing:
+            tr[1].record()
+        if timed:
+            ev[3].record()
+        res, done = solve_part(g, n, fr, slot, timed, host_out, gather)
+        if tracing:
+            trace.append((g, slot, tr + [done]))
         return res
 
     def sync():
@@ -275,6 +303,14 @@ def main():
         if i > 0:
             for j, k in enumerate(list(kern_ms)):
                 kern_ms[k] += ev[j].elapsed_time(ev[j + 1]) / (n_probe - 1)
+    groups = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
+    # un-timed set-up: every launch stream sees one group of every size the timed region will give it, so that the
+    # memory pools torch keeps per stream are filled before the clock starts (a first allocation on a stream is a
+    # device-wide synchronisation in the middle of the pipeline)
+    for slot, g in sorted({(k % n_streams, g) for k, g in enumerate(groups)}):
+        with torch.cuda.stream(streams[slot]):
+            one_group(g, slot=slot)
+    sync()
     done, k = 0, 0
     while done < args.warmup:
         g = min(G, args.warmup - done)
@@ -282,9 +318,11 @@ def main():
             one_group(g, slot=k % n_streams)
         done += g
         k += 1
-    groups = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
     host_res = [torch.empty(world * g * B, 7).pin_memory() for g in groups]
     sync()
+    if trace is not None:
+        trace_t0 = torch.cuda.Event(enable_timing=True)
+        trace_t0.record()
     # timed: exactly `steps` batches of B images per GPU, G at a time; every result is copied to the host
     t0 = time.perf_counter()
     for k, (g, out) in enumerate(zip(groups, host_res)):
@@ -292,6 +330,11 @@ def main():
             one_group(g, host_out=out, slot=k % n_streams)
     sync()
     elapsed = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        for g, slot, tr in trace:
+            print(f"trace: group of {g} on stream {slot}: front starts {trace_t0.elapsed_time(tr[0]):.2f} ms, solve queued behind "
+                  f"{trace_t0.elapsed_time(tr[1]):.2f} ms, solve ends {trace_t0.elapsed_time(tr[2]):.2f} ms", file=sys.stderr)
+        print(f"trace: timed region {elapsed * 1e3:.2f} ms", file=sys.stderr)
     res = host_res[0][:B]
     if grouped:
         tmax = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
@@ -339,21 +382,33 @@ def main():
 
         # ---- counters of the same launch shape from the committed rocprofv3 --pmc passes (bench.py cannot profile itself) ----
         traffic = valu = grid_mfma_busy = None
-        cpath = os.path.join(ROOT, "profiles", "r2_solve_counters.json")
-        if os.path.exists(cpath):
+        import glob
+        counters, exact = None, False
+        for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_solve_counters*.json"))):
             with open(cpath) as fh:
                 cj = json.load(fh)
-            if (cj.get("hypotheses_per_launch") == n_hyp and cj.get("adam_steps") == EPOCHS
-                    and cj.get("on_demand_table") == (not args.complete_table)):
-                traffic = (cj["fetch_size_kb_per_launch"] + cj["write_size_kb_per_launch"]) * 1024.0
-                # vector issue: a SIMD issues one wave-instruction per 2 cycles (64 lanes over a 32-wide unit)
-                peak_issue = cj["compute_units"] * 4 * cj["shader_clock_ghz"] * 1e9 / 2
-                valu = {"wave_instructions_per_launch": cj["sq_insts_valu_per_launch"], "peak_per_sec": peak_issue,
-                        "frac": cj["sq_insts_valu_per_launch"] / (solve_ms * 1e-3) / peak_issue,
-                        "model": f"{cj['compute_units']} CUs x 4 SIMDs x {cj['shader_clock_ghz']} GHz / 2 cycles per wave-instruction",
-                        "source": "profiles/r2_solve_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
-            if cj.get("grid_mfma", {}).get("images_per_launch") == n_img:
-                grid_mfma_busy = cj["grid_mfma"].get("mfma_busy_frac")
+            if cj.get("adam_steps") != EPOCHS or cj.get("on_demand_table") != (not args.complete_table):
+                continue
+            if cj.get("hypotheses_per_launch") == n_hyp:
+                counters, exact, csrc = cj, True, os.path.relpath(cpath, ROOT)
+                break
+            if counters is None:
+                counters, csrc = cj, os.path.relpath(cpath, ROOT)
+        if counters is not None:
+            # the same kernel on the same scene does the same work per hypothesis: a profile of another launch size is scaled
+            cj, scale = counters, n_hyp / counters["hypotheses_per_launch"]
+            how = "" if exact else f", scaled from a launch of {cj['hypotheses_per_launch']} hypotheses"
+            traffic = (cj["fetch_size_kb_per_launch"] + cj["write_size_kb_per_launch"]) * 1024.0 * scale
+            # vector issue: a SIMD issues one wave-instruction per 2 cycles (64 lanes over a 32-wide unit)
+            peak_issue = cj["compute_units"] * 4 * cj["shader_clock_ghz"] * 1e9 / 2
+            valu = {"wave_instructions_per_launch": cj["sq_insts_valu_per_launch"] * scale, "peak_per_sec": peak_issue,
+                    "frac": cj["sq_insts_valu_per_launch"] * scale / (solve_ms * 1e-3) / peak_issue,
+                    "model": f"{cj['compute_units']} CUs x 4 SIMDs x {cj['shader_clock_ghz']} GHz / 2 cycles per wave-instruction",
+                    "source": f"{csrc} (rocprofv3 --pmc SQ_INSTS_VALU{how})"}
+            traffic_source = f"{csrc} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch{how})"
+            grid_mfma_busy = cj.get("grid_mfma", {}).get("mfma_busy_frac")
+        else:
+            traffic_source = None
 
         # ---- the kernels in front of the solve: algorithmic bytes / flops of one launch over n_img images ----
         front = {}
@@ -404,7 +459,7 @@ def main():
                          "algorithmic_bytes_per_launch": solve_algo,
                          "census": {"covered_pixels_per_step": covered, "table_tiles_computed": tiles, "pixel_tiles_touched": pixel_tiles,
                                     "table_fraction_computed": None if tiles is None else tiles * 1024 / (n_img * math.prod(ops.table_shape(mod.mesh, 1, H * W)))},
-                         "traffic_source": "profiles/r2_solve_counters.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch)",
+                         "traffic_source": traffic_source,
                          "valu_issue": valu,
                          "note": "algorithmic bytes of the implemented design: 300 steps x covered pixels x 16 B (three table entries + clutter "
                                  "score per covered pixel) + computed table tiles x 4 KB + touched pixel tiles x 16 KB of feature map + the "

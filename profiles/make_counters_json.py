@@ -2,7 +2,7 @@
 """Condenses the CSV summaries of one `collect.sh` run into the JSON that bench.py reads for `roofline.traffic`,
 `roofline.valu_issue` and the matrix-core utilisation of the grid scoring.
 
-    python profiles/make_counters_json.py <dir with kernel_stats.csv, pmc_*.csv> <tag> <out.json>
+    python profiles/make_counters_json.py <dir with kernel_stats.csv, pmc_*.csv> <tag> <out.json> [hypotheses per launch, default 512]
 
 Per-launch values: a --pmc CSV row holds the sum over all dispatch rows of a kernel (rocprofv3 writes one row per
 launch and counter instance), so a per-launch value is Total / launches, launches taken from the FETCH_SIZE pass
@@ -20,7 +20,8 @@ def rows(path):
         return list(csv.DictReader(fh))
 
 
-def main(d, tag, out):
+def main(d, tag, out, n_hyp=512):
+    n_hyp = int(n_hyp)
     stats = {r["Name"]: r for r in rows(f"{d}/kernel_stats.csv")}
     pmc = {}
     for name in ("fetch_size", "write_size", "sq", "mfma"):
@@ -50,7 +51,7 @@ def main(d, tag, out):
         "tag": tag,
         "command": "bash profiles/collect.sh (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE | WRITE_SIZE | SQ_* | MFMA counters, one run each, "
                    "on python3 bench.py --no-cpu-baseline --streams 1)",
-        "kernel": solve, "hypotheses_per_launch": 512, "adam_steps": 300, "on_demand_table": "ILb1ELb0ELb1E" in solve or "ILb0ELb0ELb1E" in solve,
+        "kernel": solve, "hypotheses_per_launch": n_hyp, "adam_steps": 300, "on_demand_table": "ILb1ELb0ELb1E" in solve or "ILb0ELb0ELb1E" in solve,
         "compute_units": COMPUTE_UNITS,
         "avg_duration_ms": float(stats[solve]["AverageNs"]) / 1e6,
         "shader_clock_ghz": round(clock_ghz(solve), 3),
@@ -67,7 +68,7 @@ def main(d, tag, out):
                 "applies to wide streaming reads, this kernel mostly gathers single 16-byte table elements, so the raw value is kept. The writes "
                 "are the computed table tiles, the register spills (scratch) and the results.",
         "grid_mfma": {
-            "kernel": mfma, "images_per_launch": 512, "avg_duration_ms": float(stats[mfma]["AverageNs"]) / 1e6,
+            "kernel": mfma, "images_per_launch": n_hyp, "avg_duration_ms": float(stats[mfma]["AverageNs"]) / 1e6,
             "shader_clock_ghz": round(clock_ghz(mfma), 3),
             "sq_insts_mfma_per_launch": per_launch(mfma, "SQ_INSTS_MFMA"),
             "sq_valu_mfma_busy_cycles_per_launch": per_launch(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"),
@@ -85,4 +86,4 @@ def main(d, tag, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
