@@ -24,7 +24,7 @@
 namespace nemo {
 
 constexpr int GM_CHUNK = 32;        // pixels per workgroup
-constexpr int GM_RBG = 9;           // row blocks (of 32 poses) accumulated per launch slice at most (16 result registers each)
+constexpr int GM_RBG = 6;           // row blocks (of 32 poses) accumulated per launch slice at most (16 result registers each; nine spill)
 
 // ---------------------------------------------------------------------------------------------
 // one-off: pre-rendered maps [N, C, HW] f32 -> packed fragments
@@ -360,10 +360,7 @@ static void launch_mfma_nks(const void* packed, const void* featp, const float* 
             case 3: launch_mfma_slice<NKS, 3>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
             case 4: launch_mfma_slice<NKS, 4>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
             case 5: launch_mfma_slice<NKS, 5>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
-            case 6: launch_mfma_slice<NKS, 6>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
-            case 7: launch_mfma_slice<NKS, 7>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
-            case 8: launch_mfma_slice<NKS, 8>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
-            default: launch_mfma_slice<NKS, 9>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
+            default: launch_mfma_slice<NKS, 6>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
         }
     }
 }
