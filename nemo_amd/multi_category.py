@@ -89,9 +89,13 @@ class MultiCategorySolver:
             if not 0 <= cat < len(self.grids):
                 continue                         # no such category: the solve answers that pair with a NaN row
             rows = torch.nonzero(pair_category == cat).reshape(-1)
-            imgs = pair_image[rows].to(dev)
+            imgs = pair_image[rows]
             maps, cs, ths = self.grids[cat]
-            C_, th_, pr_ = initial_poses(fm[imgs].contiguous(), clutter_score[imgs].contiguous(), cams, cs, ths, maps,
+            if imgs.numel() == b and bool(torch.equal(imgs, torch.arange(b))):      # every image, in order: no copies
+                fm_c, clu_c = fm, clutter_score
+            else:
+                fm_c, clu_c = fm[imgs.to(dev)].contiguous(), clutter_score[imgs.to(dev)].contiguous()
+            C_, th_, pr_ = initial_poses(fm_c, clu_c, cams, cs, ths, maps,
                                          principal=self.principal_samples if self.dof == 6 else None, dof=self.dof)
             init_C[rows.to(dev)], init_theta[rows.to(dev)] = C_, th_
             if init_principal is not None:
@@ -123,13 +127,30 @@ class MultiCategorySolver:
         preds, _ = self.solve_pairs(feature_map, torch.arange(labels.numel()), labels, **kw)
         return preds
 
+    max_workspace_bytes = 64 << 30      # classify() splits the batch so that one launch's similarity-tile workspace stays below this
+
     def classify(self, feature_map, **kw):
         """Render-and-compare classification: every image against every category.
-        -> (category name per image, final losses [B, n_categories] (numpy), predictions [B][n_categories])."""
+        -> (category name per image, final losses [B, n_categories] (numpy), predictions [B][n_categories]).
+        The batch is taken in slices of as many images as fit the workspace budget (the tile workspace holds room for
+        every category's vertices per image); every slice is solved with the loss normaliser of the whole batch, so the
+        slicing does not change any result."""
         b, n_cat = feature_map.shape[0], len(self.categories)
-        pair_image = torch.arange(b).repeat_interleave(n_cat)
-        pair_category = torch.arange(n_cat).repeat(b)
-        preds, pose = self.solve_pairs(feature_map, pair_image, pair_category, **kw)
-        scores = pose[:, 6].reshape(b, n_cat).cpu().numpy()
+        hw = int(feature_map.shape[2] * feature_map.shape[3])
+        per_image = ops.solve_workspace_bytes(self.mesh, 1, hw) or 4 * int(np.prod(ops.table_shape(self.mesh, 1, hw)))
+        step = max(1, min(b, int(self.max_workspace_bytes // max(per_image, 1))))
+        step = -(-b // -(-b // step))            # slices of equal size
+        kw.setdefault("global_batch", b)
+        preds, scores = [], []
+        for i0 in range(0, b, step):
+            n = min(step, b - i0)
+            pair_image = torch.arange(n).repeat_interleave(n_cat)
+            pair_category = torch.arange(n_cat).repeat(n)
+            bbox = kw.get("bbox")
+            kw_i = dict(kw, bbox=None if bbox is None else bbox[i0:i0 + n])
+            p_, pose = self.solve_pairs(feature_map[i0:i0 + n], pair_image, pair_category, **kw_i)
+            preds += p_
+            scores.append(pose[:, 6].reshape(n, n_cat).cpu().numpy())
+        scores = np.concatenate(scores)
         names = [self.categories[j] for j in scores.argmin(axis=1)]
         return names, scores, [preds[i * n_cat:(i + 1) * n_cat] for i in range(b)]

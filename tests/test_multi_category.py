@@ -132,6 +132,11 @@ def test_render_compare_classification(gpu):
     assert np.abs(ref_scores - scores).max() < 2e-3, (ref_scores, scores)
     assert list(ref_scores.argmin(axis=1)) == list(scores.argmin(axis=1)) == [i % n_cat for i in range(B)]
     assert names == [f"cat{i % n_cat}" for i in range(B)]
+    # a workspace budget that forces one image per launch: the same scores, bit for bit
+    solver.max_workspace_bytes = 1
+    names1, scores1, preds1 = solver.classify(fm.to(gpu))
+    solver.max_workspace_bytes = type(solver).max_workspace_bytes
+    assert names1 == names and np.array_equal(scores1, scores) and preds1[1][2]["final"] == preds[1][2]["final"]
     # a pair that names no category gets a NaN row, the others are untouched
     _, pose = solver.solve_pairs(fm.to(gpu), torch.tensor([0, 1]), torch.tensor([0, 7]))
     assert torch.isnan(pose[1]).all() and float(pose[0, 6]) == float(scores[0, 0])
