@@ -181,6 +181,18 @@ int nemo_clutter_grid_score_packed(const void* packed, const float* feat, const 
                                    int32_t C, int32_t HW, float* out_clutter_score, float* out_loss, int32_t* out_argmin,
                                    float* out_min, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Scoring the same batch against several pose grids (one per category, scripts/inference.py:29-96 and
+ * nemo_cls.py:262-282 score every category's grid on the same feature maps): nemo_grid_score_packed and
+ * nemo_clutter_grid_score_packed leave the batch's operand fragments in the first nemo_grid_fragments_bytes(B, C, HW)
+ * bytes of their workspace; nemo_grid_score_fragments scores another packed grid (same C and HW) on them without
+ * reading the maps again.  Outputs as nemo_grid_score_packed, bit for bit; workspace (the partial sums):
+ * nemo_grid_score_fragments_workspace(N, B, HW) bytes. */
+size_t nemo_grid_fragments_bytes(int32_t B, int32_t C, int32_t HW);
+size_t nemo_grid_score_fragments_workspace(int32_t N, int32_t B, int32_t HW);
+int nemo_grid_score_fragments(const void* packed, const void* fragments, const float* clu, int32_t N, int32_t B, int32_t C,
+                              int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* Scoring of re-centred copies of a batch, the 6-D initialisation loop of batch_solve_pose.py:264-295 (every
  * principal-point sample re-centres the whole batch with align_no_centered, :65-90, and scores it against the
  * grid): virtual image bv is source image bv % B_src resampled with (dist_src, dist_tgt, p_src, p_tgt)[bv] as

@@ -17,7 +17,7 @@ SYMBOLS = [
     "nemo_last_error", "nemo_version", "nemo_mesh_create", "nemo_mesh_set_memory", "nemo_mesh_destroy",
     "nemo_mesh_info", "nemo_mesh_set_parts", "nemo_solve_parts", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
     "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_score_static", "nemo_grid_pack_bytes", "nemo_grid_pack",
-    "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_clutter_grid_score_packed", "nemo_grid_score_recentred_workspace",
+    "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_clutter_grid_score_packed", "nemo_grid_fragments_bytes", "nemo_grid_score_fragments_workspace", "nemo_grid_score_fragments", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
     "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
     "nemo_solve_features_workspace", "nemo_solve_features",
@@ -68,6 +68,11 @@ def load():
     lib.nemo_grid_score_packed_workspace.argtypes = [i32, i32, i32, i32]
     lib.nemo_grid_score_packed_workspace.restype = C.c_size_t
     lib.nemo_grid_score_packed.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, f32p, vp, f32p, vp, C.c_size_t, vp]
+    lib.nemo_grid_fragments_bytes.argtypes = [i32, i32, i32]
+    lib.nemo_grid_fragments_bytes.restype = C.c_size_t
+    lib.nemo_grid_score_fragments_workspace.argtypes = [i32, i32, i32]
+    lib.nemo_grid_score_fragments_workspace.restype = C.c_size_t
+    lib.nemo_grid_score_fragments.argtypes = [vp, vp, f32p, i32, i32, i32, i32, f32p, vp, f32p, vp, C.c_size_t, vp]
     lib.nemo_clutter_grid_score_packed.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, i32, f32p, f32p, vp, f32p, vp, C.c_size_t, vp]
     lib.nemo_grid_score_recentred_workspace.argtypes = [i32, i32, i32, i32, i32]
     lib.nemo_grid_score_recentred_workspace.restype = C.c_size_t
@@ -99,7 +104,8 @@ def load():
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("nemo_last_error", "nemo_version", "nemo_grid_score_workspace", "nemo_similarity_table_elems",
-                        "nemo_grid_pack_bytes", "nemo_grid_score_packed_workspace", "nemo_grid_score_recentred_workspace",
+                        "nemo_grid_pack_bytes", "nemo_grid_score_packed_workspace", "nemo_grid_score_recentred_workspace", "nemo_grid_fragments_bytes",
+                        "nemo_grid_score_fragments_workspace",
                         "nemo_solve_features_workspace"):
             fn.restype = C.c_int
     _lib = lib

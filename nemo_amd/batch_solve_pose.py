@@ -51,9 +51,14 @@ def get_init_pos_rendered_dim0(samples_maps, samples_pos, samples_theta, predict
     """(init campos [b,3], init theta [b], min loss [b]) - arg-min of the grid loss per image.
     `batch_size` (the reference's chunk size) is accepted and ignored: nothing is chunked.
     With top_k > 1 the k lowest-loss grid poses of every image come back instead, best first:
-    (campos [b,k,3], theta [b,k], loss [b,k]); column 0 is the arg-min pose."""
-    pre = samples_maps.squeeze(1) if samples_maps.dim() == 5 else samples_maps
-    loss, idx, mn = ops.grid_score(pre, predicted_maps, clutter_scores, packed=getattr(samples_maps, "_nemo_packed_grid", None))
+    (campos [b,k,3], theta [b,k], loss [b,k]); column 0 is the arg-min pose.
+    grid_scores: (loss [b,N], argmin [b], min [b]) of these very maps against this grid when the caller has them already
+    (ops.clutter_and_grid_score, ops.grid_score_on_fragments): nothing is scored again."""
+    if grid_scores is not None:
+        loss, idx, mn = grid_scores
+    else:
+        pre = samples_maps.squeeze(1) if samples_maps.dim() == 5 else samples_maps
+        loss, idx, mn = ops.grid_score(pre, predicted_maps, clutter_scores, packed=getattr(samples_maps, "_nemo_packed_grid", None))
     if top_k > 1:
         if top_k > loss.shape[1]:
             raise ValueError(f"top_k={top_k} exceeds the {loss.shape[1]} poses of the grid")

@@ -395,6 +395,20 @@ int launch_grid_mfma_clutter(const void* packed, const float* feat, const float*
     return 0;
 }
 
+// Scoring alone, on fragments built by an earlier call for the same maps.
+int launch_grid_mfma_fragments(const void* packed, const void* featp, const float* clu, int N, int B, int C, int HW, float* partial,
+                               hipStream_t st) {
+    if ((B + 31) / 32 > 65535) return -1;
+    switch (C / 16) {
+        case 1: launch_mfma_nks<1>(packed, featp, clu, N, B, HW, partial, st); break;
+        case 2: launch_mfma_nks<2>(packed, featp, clu, N, B, HW, partial, st); break;
+        case 4: launch_mfma_nks<4>(packed, featp, clu, N, B, HW, partial, st); break;
+        case 8: launch_mfma_nks<8>(packed, featp, clu, N, B, HW, partial, st); break;
+        default: return -2;
+    }
+    return 0;
+}
+
 // featp: grid_feat_bytes(B, C, HW) bytes of scratch; partial: grid_chunks(HW) * B * N floats.
 int launch_grid_mfma(const void* packed, const float* feat, const float* clu, int N, int B, int C, int HW, void* featp,
                      float* partial, hipStream_t st) {

@@ -845,6 +845,8 @@ int launch_grid_mfma(const void* packed, const float* feat, const float* clu, in
                      float* partial, hipStream_t st);
 int launch_grid_mfma_clutter(const void* packed, const float* feat, const float* clutter, int K, int N, int B, int C, int HW,
                              float* out_clu, void* featp, float* partial, hipStream_t st);
+int launch_grid_mfma_fragments(const void* packed, const void* featp, const float* clu, int N, int B, int C, int HW, float* partial,
+                               hipStream_t st);
 }
 
 extern "C" size_t nemo_grid_pack_bytes(int32_t N, int32_t C, int32_t HW) {
@@ -885,6 +887,37 @@ extern "C" int nemo_grid_score_packed(const void* packed, const float* feat, con
         return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_packed: batch too large for one launch");
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)partial, clu, N, B, HW, nemo::grid_chunks(HW),
+                       out_loss, out_argmin, out_min);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+extern "C" size_t nemo_grid_fragments_bytes(int32_t B, int32_t C, int32_t HW) {
+    if (B <= 0 || C <= 0 || HW <= 0 || !nemo::grid_mfma_supported(C)) return 0;
+    return nemo::grid_feat_bytes(B, C, HW);
+}
+
+extern "C" size_t nemo_grid_score_fragments_workspace(int32_t N, int32_t B, int32_t HW) {
+    if (N <= 0 || B <= 0 || HW <= 0) return 0;
+    return (size_t)nemo::grid_chunks(HW) * B * N * sizeof(float);
+}
+
+extern "C" int nemo_grid_score_fragments(const void* packed, const void* fragments, const float* clu, int32_t N, int32_t B, int32_t C,
+                                         int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!packed || !fragments || !out_argmin || N <= 0 || B < 0 || C <= 0 || HW <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_fragments: bad argument");
+    if (!nemo::grid_mfma_supported(C))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_fragments: %d channels (takes 16, 32, 64 or 128)", C);
+    const size_t need = nemo_grid_score_fragments_workspace(N, B, HW);
+    if (!workspace || workspace_bytes < need)
+        return fail(NEMO_ERR_INVALID, "nemo_grid_score_fragments: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (nemo::launch_grid_mfma_fragments(packed, fragments, clu, N, B, C, HW, (float*)workspace, st))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_grid_score_fragments: batch too large for one launch");
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grid_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)workspace, clu, N, B, HW, nemo::grid_chunks(HW),
                        out_loss, out_argmin, out_min);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;

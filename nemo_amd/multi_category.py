@@ -77,7 +77,21 @@ class MultiCategorySolver:
         epochs = int(cfg.inference.epochs)
         times = {}
         t0 = time.time()
-        clutter_score = ops.clutter_score(fm, _clutter_rows(self.clutter_bank, c))
+        cats = [cat for cat in sorted(set(pair_category.tolist())) if 0 <= cat < len(self.grids)]   # others: the solve answers with a NaN row
+        rows_of = {cat: torch.nonzero(pair_category == cat).reshape(-1) for cat in cats}
+        whole = {cat: rows_of[cat].numel() == b and bool(torch.equal(pair_image[rows_of[cat]], torch.arange(b))) for cat in cats}
+        packs = {cat: getattr(self.grids[cat][0], "_nemo_packed_grid", None) for cat in cats}
+        # Categories that see every image, in order, share one conversion of the maps into the scoring's operand
+        # fragments (3-D: the batch is scored as it is): the first of them scores the clutter vectors in the same pass.
+        shared = [cat for cat in cats if whole[cat] and packs[cat] is not None and self.dof != 6]
+        frag_ws, grid_scores = None, {}
+        if shared:
+            first = shared[0]
+            frag_ws = torch.empty(ops.grid_score_workspace_bytes(packs[first], b), dtype=torch.uint8, device=dev)
+            clutter_score, l_, i_, m_ = ops.clutter_and_grid_score(fm, _clutter_rows(self.clutter_bank, c), packs[first], workspace=frag_ws)
+            grid_scores[first] = (l_, i_, m_)
+        else:
+            clutter_score = ops.clutter_score(fm, _clutter_rows(self.clutter_bank, c))
         t1 = time.time()
         times["pre_compute_time"] = t1 - t0
         # initial poses: one grid scoring per category, over the images paired with it
@@ -85,18 +99,19 @@ class MultiCategorySolver:
         init_theta = torch.zeros(n_pairs, device=dev)
         init_principal = torch.zeros(n_pairs, 2, device=dev) if self.dof == 6 else None
         cams = self.rasterizer.cameras
-        for cat in sorted(set(pair_category.tolist())):
-            if not 0 <= cat < len(self.grids):
-                continue                         # no such category: the solve answers that pair with a NaN row
-            rows = torch.nonzero(pair_category == cat).reshape(-1)
+        for cat in cats:
+            rows = rows_of[cat]
             imgs = pair_image[rows]
             maps, cs, ths = self.grids[cat]
-            if imgs.numel() == b and bool(torch.equal(imgs, torch.arange(b))):      # every image, in order: no copies
+            if whole[cat]:                       # every image, in order: no copies
                 fm_c, clu_c = fm, clutter_score
+                if cat in shared and cat not in grid_scores:
+                    grid_scores[cat] = ops.grid_score_on_fragments(packs[cat], frag_ws, b, clutter_score)
             else:
                 fm_c, clu_c = fm[imgs.to(dev)].contiguous(), clutter_score[imgs.to(dev)].contiguous()
             C_, th_, pr_ = initial_poses(fm_c, clu_c, cams, cs, ths, maps,
-                                         principal=self.principal_samples if self.dof == 6 else None, dof=self.dof)
+                                         principal=self.principal_samples if self.dof == 6 else None, dof=self.dof,
+                                         grid_scores=grid_scores.get(cat))
             init_C[rows.to(dev)], init_theta[rows.to(dev)] = C_, th_
             if init_principal is not None:
                 init_principal[rows.to(dev)] = pr_

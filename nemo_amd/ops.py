@@ -289,6 +289,29 @@ def clutter_and_grid_score(feature_map, clutter, packed, workspace=None):
     return clu, loss, amin, mn
 
 
+def grid_score_on_fragments(packed, fragments_workspace, B, clutter_score_map=None):
+    """grid_score(..., packed=packed) for a batch whose operand fragments an earlier grid_score / clutter_and_grid_score
+    call with `workspace=fragments_workspace` has left in that workspace (same B, channels and map size): the maps are not
+    read again.  Bit for bit the result of grid_score.  -> (loss [B,N], argmin [B] int32, min_loss [B])."""
+    lib = _lib.load()
+    N, Cc, H, W = packed.shape
+    need = int(lib.nemo_grid_fragments_bytes(B, Cc, H * W))
+    if fragments_workspace.dtype != torch.uint8 or fragments_workspace.numel() < need or not fragments_workspace.is_contiguous():
+        raise ValueError(f"fragments_workspace must be the uint8 workspace (at least {need} bytes) of a grid scoring of the same batch")
+    dev = fragments_workspace.device
+    clu = None if clutter_score_map is None else f32c(clutter_score_map).reshape(B, H * W)
+    loss = torch.empty(B, N, device=dev)
+    amin = torch.empty(B, dtype=torch.int32, device=dev)
+    mn = torch.empty(B, device=dev)
+    nbytes = int(lib.nemo_grid_score_fragments_workspace(N, B, H * W))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nemo_grid_score_fragments(ptr(packed.data, torch.uint8), ptr(fragments_workspace, torch.uint8), ptr(clu), N, B, Cc, H * W,
+                                            ptr(loss), ptr(amin, torch.int32), ptr(mn), ptr(ws, torch.uint8), nbytes, stream_ptr()),
+              "nemo_grid_score_fragments")
+    return loss, amin, mn
+
+
 def grid_score_workspace_bytes(packed, B):
     """Bytes of the workspace grid_score / clutter_and_grid_score need for B images against a packed grid."""
     N, Cc, H, W = packed.shape

@@ -260,6 +260,17 @@ def test_clutter_and_grid_score_in_one_pass(which, n_img, n_clutter, request):
         assert torch.equal(clu3, clu) and torch.equal(loss3, loss) and torch.equal(amin3, amin)
     with pytest.raises(ValueError):
         ops.clutter_and_grid_score(fm, bank, packed, workspace=ws[:16])
+    # a second grid scored on the fragments the call left in the workspace: what grid_score gives on the maps
+    maps_b, _, _ = nemo_amd.get_pre_render_samples(sc.mod, az[1::3], el, th, di)
+    packed_b = ops.grid_pack(maps_b.squeeze(1))
+    want = ops.grid_score(None, fm, clu, packed=packed_b)
+    got = ops.grid_score_on_fragments(packed_b, ws, n_img, clu)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    want_fg = ops.grid_score(None, fm, None, packed=packed_b)
+    got_fg = ops.grid_score_on_fragments(packed_b, ws, n_img)
+    assert all(torch.equal(a, b) for a, b in zip(got_fg, want_fg))
+    with pytest.raises(ValueError):
+        ops.grid_score_on_fragments(packed_b, ws[:16], n_img, clu)
 
 
 def test_render_backward_matches_autograd(small):
