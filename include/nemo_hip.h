@@ -303,6 +303,10 @@ int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table
  * image.  C must be 16, 32, 64 or 128 (the workspace size is 0 and the call returns NEMO_ERR_UNSUPPORTED otherwise:
  * use nemo_similarity_table + nemo_solve). */
 size_t nemo_solve_features_workspace(nemo_mesh_t mesh, int32_t n_img, int32_t HW);
+/* 1 when nemo_solve_features takes this mesh on an H x W map (channel count, and the presence maps of the tiles fit
+ * the workgroup's LDS beside the rasteriser's buffers: meshes of a few thousand vertices per part), else 0: then use
+ * nemo_similarity_table + nemo_solve.  with_parts != 0: for calls with hyp_to_part (the largest part counts). */
+int nemo_solve_features_supported(nemo_mesh_t mesh, int32_t H, int32_t W, int32_t with_parts);
 int nemo_solve_features(nemo_mesh_t mesh, const nemo_camera* cam, const float* feat, void* workspace, size_t workspace_bytes,
                         const float* clutter_score, const int32_t* hyp_to_image, const int32_t* hyp_to_part,
                         const float* init_campos, const float* init_theta, const float* init_principal,

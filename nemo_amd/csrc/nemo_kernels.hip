@@ -1415,6 +1415,18 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
+// The sizes the optimisation loop's LDS plan is made for: the whole handle, or its largest part.
+static void solve_plan_sizes(const nemo_mesh_s* m, bool use_parts, int* lay_v, int* lay_f, int* lay_blocks) {
+    *lay_v = m->V; *lay_f = m->F; *lay_blocks = ((m->V - 1) >> 5) + 1;
+    if (!use_parts) return;
+    *lay_v = *lay_f = *lay_blocks = 0;
+    for (const nemo::MeshPart& q : m->parts) {
+        *lay_v = q.nv > *lay_v ? q.nv : *lay_v; *lay_f = q.nf > *lay_f ? q.nf : *lay_f;
+        const int nb = ((q.v0 + q.nv - 1) >> 5) - (q.v0 >> 5) + 1;
+        *lay_blocks = nb > *lay_blocks ? nb : *lay_blocks;
+    }
+}
+
 // `feat` non-null: the similarity table is computed on demand by the kernel (`table` = workspace that need not be
 // initialised); feat null: `table` is the complete table of nemo_similarity_table.
 static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, float* table, const float* clu,
@@ -1434,18 +1446,13 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, 
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     // LDS plan: for the whole handle, or for its largest part when every hypothesis renders one part
-    int lay_v = m->V, lay_f = m->F, lay_blocks = ((m->V - 1) >> 5) + 1;
+    int lay_v, lay_f, lay_blocks;
     a.parts = nullptr; a.hyp_to_part = nullptr; a.n_parts = 1;
     if (hyp_to_part) {
         if (m->parts.empty()) return fail(NEMO_ERR_STATE, "nemo_solve_parts: the mesh has no parts (call nemo_mesh_set_parts)");
-        lay_v = lay_f = lay_blocks = 0;
-        for (const nemo::MeshPart& q : m->parts) {
-            lay_v = q.nv > lay_v ? q.nv : lay_v; lay_f = q.nf > lay_f ? q.nf : lay_f;
-            const int nb = ((q.v0 + q.nv - 1) >> 5) - (q.v0 >> 5) + 1;
-            lay_blocks = nb > lay_blocks ? nb : lay_blocks;
-        }
         a.parts = m->d_parts; a.hyp_to_part = hyp_to_part; a.n_parts = (int)m->parts.size();
     }
+    solve_plan_sizes(m, hyp_to_part != nullptr, &lay_v, &lay_f, &lay_blocks);
     const int HW = cam->H * cam->W;
     a.feat = feat; a.bank = nullptr; a.apiece = 0; a.meta = nullptr; a.nks = 0;
     a.nfb = (lay_f + (1 << kFaceBlockShift) - 1) >> kFaceBlockShift;
@@ -1501,6 +1508,19 @@ extern "C" int nemo_solve_parts(nemo_mesh_t m, const nemo_camera* cam, const flo
     if (!hyp_to_part) return fail(NEMO_ERR_INVALID, "nemo_solve_parts: hyp_to_part is required (nemo_solve renders the whole handle)");
     return solve_impl(m, cam, nullptr, const_cast<float*>(table), clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes,
                       n_hyp, n_img, global_batch, dof, opt, out_pose, out_hist, hyp_to_part, stream);
+}
+
+extern "C" int nemo_solve_features_supported(nemo_mesh_t m, int32_t H, int32_t W, int32_t with_parts) {
+    if (!m || H <= 0 || W <= 0 || !m->bank_frag || (with_parts && m->parts.empty())) return 0;
+    if (H > kMaxSide || W > kMaxSide || m->F >= kMaxFaces) return 0;
+    int lay_v, lay_f, lay_blocks;
+    solve_plan_sizes(m, with_parts != 0, &lay_v, &lay_f, &lay_blocks);
+    const int nfb = (lay_f + (1 << kFaceBlockShift) - 1) >> kFaceBlockShift;
+    if (((H * W + 31) >> 5) >= 0xFFFF || nfb > 0xFFFF) return 0;
+    const bool packable = lay_v <= kPackedFaceVerts;
+    LdsLayout L = make_solve_layout(H, W, lay_v, lay_f, packable, kSolveThreads / 64, lay_blocks);
+    if (!packable || L.total > kMaxLds) L = make_solve_layout(H, W, lay_v, lay_f, false, kSolveThreads / 64, lay_blocks);
+    return L.total <= kMaxLds ? 1 : 0;
 }
 
 extern "C" size_t nemo_solve_features_workspace(nemo_mesh_t m, int32_t n_img, int32_t HW) {

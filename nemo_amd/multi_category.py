@@ -124,7 +124,7 @@ class MultiCategorySolver:
         skw = dict(hyp_to_image=pair_image.to(torch.int32), hyp_to_part=pair_category.to(torch.int32),
                    global_batch=b if global_batch is None else int(global_batch), dof=6 if self.dof == 6 else 3,
                    steps=epochs, lr_every=epochs // 3 if epochs >= 3 else 0, score_boxes=boxes, **adam)
-        if ops.on_demand_table_supported(self.mesh):
+        if ops.on_demand_table_supported(self.mesh, self.camera(), with_parts=True):
             # only the table tiles a pair's covered pixels need are computed (inside the solve): an image's table over
             # all categories' vertices is never built
             pose, _ = ops.solve_from_features(self.mesh, self.camera(), fm, clutter_score, init_C, init_theta, init_principal, **skw)

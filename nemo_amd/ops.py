@@ -540,9 +540,15 @@ def workspace_tables(mesh, workspace, n_img, HW):
     return workspace[:4 * n].view(torch.float32).view(shape)
 
 
-def on_demand_table_supported(mesh):
-    """True when solve_from_features takes this mesh's channel count (16, 32, 64 or 128)."""
-    return mesh.C in (16, 32, 64, 128)
+def on_demand_table_supported(mesh, cam=None, with_parts=False):
+    """True when solve_from_features takes this mesh: channel count 16, 32, 64 or 128 and, given the camera (map size),
+    tile presence maps that fit the workgroup's LDS (meshes of a few thousand vertices per part); otherwise
+    similarity_table + solve do the same job."""
+    if mesh.C not in (16, 32, 64, 128):
+        return False
+    if cam is None:
+        return True
+    return bool(_lib.load().nemo_solve_features_supported(mesh.h, int(cam.H), int(cam.W), 1 if with_parts else 0))
 
 
 def keypoint_corr(mesh, table, kp_coords, kp_vis, px_samples, py_samples, down_sample_rate, H, W):

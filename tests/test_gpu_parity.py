@@ -564,6 +564,34 @@ def test_on_demand_table_channel_counts(gpu):
                 ops.solve_from_features(sc.mod.mesh, sc.mod.camera(), fmd, clu, C0.to(gpu), th0.to(gpu), steps=40)
 
 
+def test_on_demand_table_refused_for_meshes_beyond_the_lds_plan(gpu):
+    """The tile presence maps live in LDS beside the rasteriser's buffers: for a mesh near the limit of the plain loop
+    they no longer fit, ops.on_demand_table_supported(mesh, cam) says so, solve_from_features refuses with a message and
+    similarity_table + solve still take the mesh."""
+    from nemo_amd import ops
+    H, W, C = 80, 100, 16
+    found = None
+    for nv in (4500, 5000, 5500, 6000, 6500, 7000):
+        sc = Scene(H, W, C, nv, 375.0, device=gpu)
+        if not ops.on_demand_table_supported(sc.mod.mesh, sc.mod.camera()):
+            found = sc
+            break
+        assert ops.on_demand_table_supported(sc.mod.mesh)
+    assert found is not None, "no mesh size between the two limits"
+    sc = found
+    cam = sc.mod.camera()
+    assert ops.on_demand_table_supported(sc.mod.mesh)          # the channel count alone is fine
+    g = torch.Generator().manual_seed(2)
+    fmd = torch.nn.functional.normalize(torch.randn(2, C, H, W, generator=g), dim=1).to(gpu)
+    clu = ops.clutter_score(fmd, sc.clutter.to(gpu))
+    C0, th0 = random_poses(2, seed=8, dist=(4.8, 5.2))
+    with pytest.raises(RuntimeError, match="LDS"):
+        ops.solve_from_features(sc.mod.mesh, cam, fmd, clu, C0.to(gpu), th0.to(gpu), steps=5)
+    tab = ops.similarity_table(sc.mod.mesh, fmd)
+    ref, _ = ops.solve(sc.mod.mesh, cam, tab, clu, C0.to(gpu), th0.to(gpu), steps=5)
+    assert torch.isfinite(ref).all()
+
+
 # ---- committed golden fixtures (tests/golden, made by oracle/gen_golden.py) -----------------------------
 import os
 
