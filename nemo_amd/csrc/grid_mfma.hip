@@ -253,7 +253,13 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
     constexpr int PER_THREAD = (STAGE_U4 + 64 * GM_WAVES - 1) / (64 * GM_WAVES);
     __shared__ uint4 abuf[2][STAGE_U4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.x, cb = blockIdx.y * GM_WAVES + wave;
+    // Workgroups that share a pixel chunk (the same pose fragments, different image blocks) get block ids 8 apart:
+    // workgroups are dealt round-robin over the 8 XCDs, so they run at the same time behind the same L2 and the packed
+    // grid comes from HBM once per chunk instead of once per workgroup.  id = ((chunk / 8) * ncbg + cbg) * 8 + chunk % 8.
+    const int ncbg = (ncb + GM_WAVES - 1) / GM_WAVES;
+    const int chunk = ((int)blockIdx.x / 8 / ncbg) * 8 + (int)blockIdx.x % 8, cbg = ((int)blockIdx.x / 8) % ncbg;
+    if (chunk * GM_CHUNK >= HW) return;          // padding of the last group of eight chunks (uniform over the workgroup)
+    const int cb = cbg * GM_WAVES + wave;
     const bool wave_on = cb < ncb;                               // idle waves still help with the staging
     const int cbc = wave_on ? cb : ncb - 1;
     const int b = cbc * 32 + (lane & 31), lk = lane >> 5;
@@ -343,7 +349,7 @@ template <int NKS, int NR>
 static void launch_mfma_slice(const void* packed, const void* featp, const float* clu, int N, int B, int HW, int rb0, float* partial,
                               hipStream_t st) {
     const int nrb = (N + 31) / 32, ncb = (B + 31) / 32;
-    dim3 grid(grid_chunks(HW), (ncb + GM_WAVES - 1) / GM_WAVES);
+    const dim3 grid((unsigned)(((grid_chunks(HW) + 7) / 8) * 8 * ((ncb + GM_WAVES - 1) / GM_WAVES)));
     hipLaunchKernelGGL((grid_mfma_kernel<NKS, NR>), grid, dim3(64 * GM_WAVES), 0, st, (const uint4*)packed, (const uint4*)featp, clu, N,
                        B, HW, nrb, ncb, rb0, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial);
 }
