@@ -1070,7 +1070,12 @@ template <bool FL, bool WARP, bool ONDEMAND = false>
 __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
-    const int h = blockIdx.x, tid = threadIdx.x;
+    // Runs of eight consecutive hypotheses go to workgroups whose block ids are 8 apart: workgroups are dealt
+    // round-robin over the 8 XCDs, so the hypotheses of one image (consecutive when an image has several) run at the
+    // same time behind the same L2 and share the lines of its similarity table.
+    int h = blockIdx.x;
+    if (h < (int)(gridDim.x & ~63u)) { const int b = h & 63; h = (h & ~63) + (b & 7) * 8 + (b >> 3); }
+    const int tid = threadIdx.x;
     const int H = a.rc.cc.H, W = a.rc.cc.W, HW = H * W;
     const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
     // The mesh this hypothesis renders: the whole handle, or one of its parts (uniform over the workgroup).
