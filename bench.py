@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--complete-table", action="store_true",
                     help="compute the complete vertex x pixel similarity table in front of the solve (nemo_similarity_table + "
                          "nemo_solve) instead of letting the solve compute the tiles it needs (nemo_solve_features). Default: "
-                         "tiles on demand with one hypothesis per image, the complete table with several (they share it)")
+                         "tiles on demand with one or two hypotheses per image, the complete table with more (they share it)")
     ap.add_argument("--on-demand-table", action="store_true", help="tiles on demand inside the solve whatever the number of hypotheses")
     ap.add_argument("--strong", action="store_true",
                     help=f"BASELINE configs[2]: {STRONG_TOTAL_IMAGES} images x {STRONG_HYPOTHESES} hypotheses in total, sharded over the ranks "
@@ -148,7 +148,7 @@ def main():
         args.batch, args.hypotheses, args.in_flight = STRONG_TOTAL_IMAGES // world, STRONG_HYPOTHESES, 1
     if args.complete_table and args.on_demand_table:
         raise SystemExit("--complete-table and --on-demand-table exclude each other")
-    if not args.on_demand_table and args.hypotheses > 1:
+    if not args.on_demand_table and args.hypotheses > 2:
         args.complete_table = True          # the hypotheses of an image share its table; on demand each would compute its own tiles
     # NEMO_BENCH_REHEARSAL=1: several ranks share the visible GPUs and talk over gloo, to rehearse the N > 1
     # code path on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.

@@ -116,7 +116,7 @@ def get_init_pos(inter_module, samples_pos, samples_theta, predicted_maps, clutt
         return samples_pos[idx], samples_theta[idx], torch.cat(mn)
 
 
-ON_DEMAND_MIN_IMAGES = 256       # from this many images per call on, the solve computes its similarity-table tiles itself
+ON_DEMAND_MIN_IMAGES = 256       # from this many hypotheses per call on, the solve computes its similarity-table tiles itself
 
 
 def _clutter_rows(clutter_bank, c):
@@ -287,9 +287,9 @@ def solve_pose(cfg, feature_map, inter_module, clutter_bank, cam_pos_pre_rendere
     boxes = None if bbox is None else score_boxes_from_bbox(bbox, b, n_hyp, kwargs.get("down_sample_rate", 8))
     skw = dict(global_batch=kwargs.get("global_batch", b), dof=opt_dof, steps=epochs, lr_every=epochs // 3 if epochs >= 3 else 0,
                score_boxes=boxes, **adam)
-    if n_hyp == 1 and b >= ON_DEMAND_MIN_IMAGES and ops.on_demand_table_supported(inter_module.mesh, cam):
+    if n_hyp <= 2 and b * n_hyp >= ON_DEMAND_MIN_IMAGES and ops.on_demand_table_supported(inter_module.mesh, cam):
         # the vertex x pixel similarity tiles are computed inside the solve, when a covered pixel first needs one
-        # (several hypotheses per image share the image's complete table instead: each would compute its own tiles;
+        # (three or more hypotheses per image share the image's complete table instead: each would compute its own tiles;
         # and a launch that leaves most of the chip idle has time to spare for the complete table: 0.6 ms per 64 images)
         pose, _ = ops.solve_from_features(inter_module.mesh, cam, feature_map, clutter_score, init_C, init_theta, init_principal, h2i, **skw)
     else:
