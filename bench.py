@@ -117,6 +117,9 @@ def main():
                          "nemo_solve) instead of letting the solve compute the tiles it needs (nemo_solve_features). Default: "
                          "tiles on demand with one or two hypotheses per image, the complete table with more (they share it)")
     ap.add_argument("--on-demand-table", action="store_true", help="tiles on demand inside the solve whatever the number of hypotheses")
+    ap.add_argument("--no-bulk-tiles", action="store_true",
+                    help="tiles on demand: every tile inside the loop (default: the first step's tiles and a ring of two pixels around "
+                         "them are listed by a launch that only looks and computed by one kernel in front of the loop)")
     ap.add_argument("--strong", action="store_true",
                     help=f"BASELINE configs[2]: {STRONG_TOTAL_IMAGES} images x {STRONG_HYPOTHESES} hypotheses in total, sharded over the ranks "
                          "(strong scaling: a step is one pass over all of them); overrides --batch, --hypotheses and --in-flight")
@@ -238,7 +241,8 @@ def main():
         if args.complete_table:
             pose, _ = ops.solve(mod.mesh, cam, tab, clu, cs[idx], ths[idx], hyp_to_image=h2i, **skw)
         else:           # the table tiles are computed inside the solve, when a covered pixel first needs one
-            pose, _ = ops.solve_from_features(mod.mesh, cam, x, clu, cs[idx], ths[idx], hyp_to_image=h2i, workspace=work[slot], **skw)
+            pose, _ = ops.solve_from_features(mod.mesh, cam, x, clu, cs[idx], ths[idx], hyp_to_image=h2i, workspace=work[slot],
+                                               bulk_first_step=not args.no_bulk_tiles, **skw)
         if timed:
             ev[4].record()
         done = None
@@ -307,15 +311,17 @@ def main():
     # un-timed set-up: every launch stream sees one group of every size the timed region will give it, so that the
     # memory pools torch keeps per stream are filled before the clock starts (a first allocation on a stream is a
     # device-wide synchronisation in the middle of the pipeline)
+    def run_group(k, g, host_out=None):
+        with torch.cuda.stream(streams[k % n_streams]):
+            return one_group(g, host_out=host_out, slot=k % n_streams)
+
     for slot, g in sorted({(k % n_streams, g) for k, g in enumerate(groups)}):
-        with torch.cuda.stream(streams[slot]):
-            one_group(g, slot=slot)
+        run_group(slot, g)
     sync()
     done, k = 0, 0
     while done < args.warmup:
         g = min(G, args.warmup - done)
-        with torch.cuda.stream(streams[k % n_streams]):
-            one_group(g, slot=k % n_streams)
+        run_group(k, g)
         done += g
         k += 1
     host_res = [torch.empty(world * g * B, 7).pin_memory() for g in groups]
@@ -326,8 +332,7 @@ def main():
     # timed: exactly `steps` batches of B images per GPU, G at a time; every result is copied to the host
     t0 = time.perf_counter()
     for k, (g, out) in enumerate(zip(groups, host_res)):
-        with torch.cuda.stream(streams[k % n_streams]):
-            one_group(g, host_out=out, slot=k % n_streams)
+        run_group(k, g, host_out=out)
     sync()
     elapsed = time.perf_counter() - t0
     if trace is not None and rank == 0:
@@ -447,7 +452,9 @@ def main():
                                    "300 Adam steps per hypothesis, random-init vertex bank",
                        "batch_per_gpu": B, "global_batch": B * world, "grid_poses": n_poses, "adam_steps": EPOCHS,
                        "batches_in_flight": G, "launch_streams": n_streams, "staggered_groups": stagger,
-                       "similarity_table": "complete, in front of the solve" if args.complete_table else "tiles on demand inside the solve",
+                       "similarity_table": "complete, in front of the solve" if args.complete_table else
+                                           ("tiles on demand inside the solve" if args.no_bulk_tiles else
+                                            "tiles on demand: the first step's (and a two-pixel ring's) by one kernel in front of the loop, the rest inside it"),
                        "clutter_score": "its own pass over the feature maps" if args.separate_clutter else "scored by the pass that builds the grid scoring's operand fragments (timed under grid_score)",
                        "hypotheses_per_image": K_HYP,
                        "partition": (f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU") +

@@ -301,7 +301,14 @@ int nemo_solve_flow(nemo_mesh_t mesh, const nemo_camera* cam, const float* table
  * layout of nemo_similarity_table (n_img * nemo_similarity_table_elems floats; only the computed tiles are written,
  * the rest stays undefined).  hyp_to_part may be NULL (whole handle).  Several hypotheses may refine against one
  * image.  C must be 16, 32, 64 or 128 (the workspace size is 0 and the call returns NEMO_ERR_UNSUPPORTED otherwise:
- * use nemo_similarity_table + nemo_solve). */
+ * use nemo_similarity_table + nemo_solve).
+ * The tiles of the first step are not computed one by one inside the loop: a launch that only looks takes every
+ * hypothesis's first step as far as its covered pixels and lists their tiles (and those of the pixels two columns /
+ * rows around them, which the next steps are likely to reach), one kernel computes the listed tiles, and the loop
+ * starts with them present.  The lists (one bit per tile and hypothesis) live behind the tables in the workspace:
+ * nemo_solve_features_workspace leaves room for two hypotheses per image; a call with more hypotheses than the
+ * workspace has room for, or with a workspace that holds the tables alone, computes every tile inside the loop.
+ * Results are the same bit for bit either way. */
 size_t nemo_solve_features_workspace(nemo_mesh_t mesh, int32_t n_img, int32_t HW);
 /* 1 when nemo_solve_features takes this mesh on an H x W map (channel count, and the presence maps of the tiles fit
  * the workgroup's LDS beside the rasteriser's buffers: meshes of a few thousand vertices per part), else 0: then use

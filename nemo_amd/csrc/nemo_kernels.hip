@@ -1052,6 +1052,9 @@ struct SolveArgs {
     // fragments (the two operands of the table product) and what it takes to address them; `table` is then written by the kernel
     const float* feat; const uint4* bank; size_t apiece; const BankMeta* meta; int nks, nfb;
     const MeshPart* parts; const int32_t* hyp_to_part; int n_parts;   // a handle of several meshes: hypothesis h rasterises part hyp_to_part[h]
+    // ONDEMAND with the first step's tiles computed in bulk: per hypothesis one row of mask words per 32-pixel tile naming
+    // the vertex blocks whose tiles tile_bulk_kernel computes (written by the FOOTPRINT launch, read by the loop's set-up)
+    unsigned int* need; int npt32; int dilate;
     int table_vg;                        // vertex groups of 4 per pixel tile of the table (all vertices of the handle)
     float def_px, def_py;
     float tscale, inv_tscale;    // warp mode: the reference's translation_scale (flow units per pixel) and its inverse
@@ -1066,7 +1069,9 @@ struct SolveArgs {
 // (flow_warp.py: grid_sample, align_corners=True, border padding) before it is compared with the image.
 // Two workgroups per compute unit (four waves per SIMD, 128 registers): while one hypothesis is in a serial
 // section (pose set-up, the gradient chain, Adam) or waits on LDS, the other one's waves issue.
-template <bool FL, bool WARP, bool ONDEMAND = false>
+// FOOTPRINT (with ONDEMAND): the launch in front of the loop that only looks: it takes the first step as far as the
+// covered entries and records the table tiles they read (SolveArgs::need) for tile_bulk_kernel; nothing else is written.
+template <bool FL, bool WARP, bool ONDEMAND = false, bool FOOTPRINT = false>
 __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds s = carve(smem, a.rc.L);
@@ -1097,6 +1102,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
     const int V = rc.V, vbase = rc.vbase;
     if ((unsigned)img >= (unsigned)a.n_img || (unsigned)part >= (unsigned)a.n_parts) {      // a hypothesis that names no image / no mesh: NaN row, nothing read
+        if (FOOTPRINT) return;
         if (tid < 8) a.out_pose[(size_t)h * 8 + tid] = __builtin_nanf("");
         if (a.out_hist)
             for (int k = tid; k < a.steps; k += blockDim.x) a.out_hist[(size_t)h * a.steps + k] = __builtin_nanf("");
@@ -1114,12 +1120,13 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         tc.vg_n = vg_n; tc.vb_first = vbase >> 5; tc.nvb = ((vbase + V - 1) >> 5) - tc.vb_first + 1;
         tc.nfb = a.nfb;
         build_face_block_masks<FL>(rc, s, tc);
+        if (!FOOTPRINT && a.need) preset_table_tiles(rc, s, tc, a.need + (size_t)h * a.npt32 * rc.L.mask_words, a.npt32);
     }
 
     // Adam's per-step constants (torch single-tensor path: bias corrections and step size in double, then
     // cast): step_size = -lr_k / (1 - beta1^(k+1)), sqrt(1 - beta2^(k+1)); lr_k follows the exponential schedule.
     float2* sched = (float2*)(smem + rc.L.sched);
-    for (int k = tid; k < min(a.steps, kSchedSteps); k += blockDim.x) {
+    for (int k = tid; k < (FOOTPRINT ? 0 : min(a.steps, kSchedSteps)); k += blockDim.x) {
         const double lr_k = a.lr * (a.lr_every > 0 ? pow(a.gamma, (double)(k / a.lr_every)) : 1.0);
         const double bc1 = 1.0 - pow(a.beta1, (double)(k + 1)), bc2 = 1.0 - pow(a.beta2, (double)(k + 1));
         sched[k] = make_float2((float)(-(lr_k / bc1)), (float)sqrt(bc2));
@@ -1145,7 +1152,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     // per-image constants of the loss: sum_p max(0, clu) (what an uncovered image scores) and sum_p clu
     // They are parked in the optimiser state (dedicated LDS words written once by thread 0): s.tot is
     // reused by every later reduction.
-    {
+    if (!FOOTPRINT) {
         float v2[2] = {0.0f, 0.0f};
         for (int p = tid; p < HW; p += blockDim.x) { float cl = clu[p]; v2[0] += fmaxf(0.0f, cl); v2[1] += cl; }
         block_sum<2>(v2, s.red, s.tot);
@@ -1157,7 +1164,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
     // optional crop for the reported score (rows [br0,br1) x cols [bc0,bc1) of the map)
     int br0 = 0, br1 = H, bc0 = 0, bc1 = W;
-    if (a.score_boxes) {
+    if (!FOOTPRINT && a.score_boxes) {
         br0 = max(a.score_boxes[4 * h], 0); br1 = min(a.score_boxes[4 * h + 1], H);
         bc0 = max(a.score_boxes[4 * h + 2], 0); bc1 = min(a.score_boxes[4 * h + 3], W);
         __syncthreads();
@@ -1301,6 +1308,10 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         } else {
         int first_chunk;
         const int cnt = compact_covered32(rc, s, row0, row1, &first_chunk);
+        if (FOOTPRINT) {
+            collect_table_tiles(rc, s, tc, first_chunk, cnt, a.need + (size_t)h * a.npt32 * rc.L.mask_words, a.dilate);
+            return;
+        }
         if (ONDEMAND) ensure_table_tiles(rc, s, tc, first_chunk, cnt);
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
@@ -1420,6 +1431,47 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
+// The table tiles the first step of every hypothesis reads (listed by the FOOTPRINT launch), computed in bulk in front
+// of the loop: a wave per (hypothesis, 32-pixel tile) with a non-empty row of the list, the same routine and operand
+// values as the tiles the loop computes for itself (raster.h::table_tiles_nks), with registers to spare for all the
+// channel steps of a bank fragment in flight and thousands of waves to hide the reads of the feature columns behind.
+constexpr int kBulkWaves = 4;
+// The list also takes the tiles of the pixels this many columns / rows around every covered one: the pose moves by a
+// fraction of a degree per step, and a tile computed here costs a third of one computed inside the loop, where seven
+// waves wait for the eighth.  Measured on 512 hypotheses of the 80 x 100 x 128 scene (loop + bulk kernel + the launch
+// that looks, ms): no ring 8.51 + 0.59 + 0.06, 2 pixels 8.18 + 0.75 + 0.10, 3 pixels 8.08 + 0.83 + 0.11, 4 pixels
+// 8.05 + 0.91 + 0.11; without any of it the loop takes 9.60.
+constexpr int kBulkRing = 2;
+template <int NKS>
+__global__ __launch_bounds__(64 * kBulkWaves) void tile_bulk_kernel(SolveArgs a, int mw) {
+    const int h = blockIdx.y, pt = blockIdx.x * kBulkWaves + (threadIdx.x >> 6);
+    if (pt >= a.npt32) return;
+    const unsigned int* nm = a.need + ((size_t)h * a.npt32 + pt) * mw;
+    unsigned int any = 0u;
+    for (int w = 0; w < mw; ++w) any |= nm[w];
+    if (!__builtin_amdgcn_readfirstlane((int)any)) return;
+    const int HW = a.rc.cc.H * a.rc.cc.W;
+    const int img = a.hyp_to_image ? a.hyp_to_image[h] : h;
+    int v0 = 0, nv = a.rc.V;
+    if (a.hyp_to_part) {
+        const int part = a.hyp_to_part[h];
+        if ((unsigned)part >= (unsigned)a.n_parts) return;
+        v0 = a.parts[part].v0; nv = a.parts[part].nv;
+    }
+    if ((unsigned)img >= (unsigned)a.n_img) return;
+    const int vg_n = a.table_vg, vb_first = v0 >> 5, nvb = ((v0 + nv - 1) >> 5) - vb_first + 1;
+    const float* feat = a.feat + (size_t)img * (NKS * 16) * HW;
+    float* table = a.table + (size_t)img * ((size_t)((HW + kTabTile - 1) >> kTabShift) * vg_n * kTabTile * 4);
+    const int lane = threadIdx.x & 63, lk = lane >> 5, px = lane & 31;
+    const int p = pt * 32 + px;
+    const bool pok = p < HW;
+    const float* col = feat + (pok ? p : HW - 1) + (size_t)(lk * 8) * HW;
+    const uint4* ap = a.bank + (size_t)vb_first * NKS * 64 + lane;
+    const int g0 = vb_first * 8 + lk;
+    float4* out = reinterpret_cast<float4*>(table) + ((size_t)(pt >> 2) * vg_n + g0) * 128 + (pt & 3) * 32 + px;
+    table_tiles_nks<NKS, (NKS < 4 ? NKS : 4)>(col, HW, pok, ap, a.apiece, out, a.meta->unscale, g0, vg_n, nvb, nm);
+}
+
 // The sizes the optimisation loop's LDS plan is made for: the whole handle, or its largest part.
 static void solve_plan_sizes(const nemo_mesh_s* m, bool use_parts, int* lay_v, int* lay_f, int* lay_blocks) {
     *lay_v = m->V; *lay_f = m->F; *lay_blocks = ((m->V - 1) >> 5) + 1;
@@ -1438,7 +1490,7 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, 
                       const int32_t* hyp_to_image, const float* init_campos, const float* init_theta,
                       const float* init_principal, const int32_t* score_boxes, int32_t n_hyp, int32_t n_img,
                       int32_t global_batch, int32_t dof, const nemo_adam* opt, float* out_pose, float* out_hist,
-                      const int32_t* hyp_to_part, void* stream) {
+                      const int32_t* hyp_to_part, void* stream, size_t workspace_bytes = 0) {
     if (n_hyp == 0) return NEMO_OK;
     if (!m || !table || !clu || !init_campos || !init_theta || !opt || !out_pose || n_hyp < 0 || n_img <= 0 || global_batch <= 0)
         return fail(NEMO_ERR_INVALID, "nemo_solve: bad argument");
@@ -1488,6 +1540,31 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, 
     a.lr = opt->lr; a.beta1 = opt->beta1; a.beta2 = opt->beta2; a.eps = opt->eps; a.gamma = opt->lr_gamma;
     a.out_pose = out_pose; a.out_hist = out_hist;
     a.tscale = 1.0f; a.inv_tscale = 0.0f;
+    a.need = nullptr; a.npt32 = (HW + 31) >> 5; a.dilate = 0;
+    if (feat && opt->steps > 0) {
+        // First step's tiles in bulk, when the workspace has room for the lists behind the tables: a launch that only looks
+        // (first step up to the covered entries) lists them, one kernel computes them, the loop starts with them present.
+        const size_t table_bytes = align256((size_t)n_img * table_image_elems(m->V, HW) * sizeof(float));
+        const size_t need_bytes = (size_t)n_hyp * a.npt32 * a.rc.L.mask_words * sizeof(unsigned int);
+        if (workspace_bytes >= table_bytes + need_bytes) {
+            a.need = (unsigned int*)((char*)table + table_bytes);
+            a.dilate = kBulkRing;
+            HIP_TRY(hipMemsetAsync(a.need, 0, need_bytes, (hipStream_t)stream));
+            auto look = a.rc.L.faces >= 0 ? solve_kernel<true, false, true, true> : solve_kernel<false, false, true, true>;
+            if (set_lds_limit(look, a.rc.L.total)) return NEMO_ERR_HIP;
+            hipLaunchKernelGGL(look, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
+            HIP_TRY(hipGetLastError());
+            const dim3 bg((a.npt32 + kBulkWaves - 1) / kBulkWaves, n_hyp);
+            const int mw = a.rc.L.mask_words;
+            switch (a.nks) {
+                case 1: hipLaunchKernelGGL(tile_bulk_kernel<1>, bg, dim3(64 * kBulkWaves), 0, (hipStream_t)stream, a, mw); break;
+                case 2: hipLaunchKernelGGL(tile_bulk_kernel<2>, bg, dim3(64 * kBulkWaves), 0, (hipStream_t)stream, a, mw); break;
+                case 4: hipLaunchKernelGGL(tile_bulk_kernel<4>, bg, dim3(64 * kBulkWaves), 0, (hipStream_t)stream, a, mw); break;
+                default: hipLaunchKernelGGL(tile_bulk_kernel<8>, bg, dim3(64 * kBulkWaves), 0, (hipStream_t)stream, a, mw); break;
+            }
+            HIP_TRY(hipGetLastError());
+        }
+    }
     auto kern = feat ? (a.rc.L.faces >= 0 ? solve_kernel<true, false, true> : solve_kernel<false, false, true>)
                      : (a.rc.L.faces >= 0 ? solve_kernel<true, false> : solve_kernel<false, false>);
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
@@ -1530,7 +1607,10 @@ extern "C" int nemo_solve_features_supported(nemo_mesh_t m, int32_t H, int32_t W
 
 extern "C" size_t nemo_solve_features_workspace(nemo_mesh_t m, int32_t n_img, int32_t HW) {
     if (!m || n_img <= 0 || HW <= 0 || !m->bank_frag) return 0;
-    return align256((size_t)n_img * table_image_elems(m->V, HW) * sizeof(float));
+    // the tables, and behind them the lists of the first step's tiles for up to two hypotheses per image
+    const size_t mw = (size_t)((((m->V - 1) >> 5) + 1) + 31) / 32;
+    return align256((size_t)n_img * table_image_elems(m->V, HW) * sizeof(float)) +
+           align256((size_t)2 * n_img * ((HW + 31) >> 5) * mw * sizeof(unsigned int));
 }
 
 extern "C" int nemo_solve_features(nemo_mesh_t m, const nemo_camera* cam, const float* feat, void* workspace, size_t workspace_bytes,
@@ -1539,11 +1619,15 @@ extern "C" int nemo_solve_features(nemo_mesh_t m, const nemo_camera* cam, const 
                                    const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
                                    const nemo_adam* opt, float* out_pose, float* out_hist, void* stream) {
     if (!feat || !workspace) return fail(NEMO_ERR_INVALID, "nemo_solve_features: feat and workspace are required");
-    if (m && m->bank_frag && n_img > 0 && cam && workspace_bytes < nemo_solve_features_workspace(m, n_img, cam->H * cam->W))
-        return fail(NEMO_ERR_INVALID, "nemo_solve_features: workspace of %zu bytes required, %zu given",
-                    nemo_solve_features_workspace(m, n_img, cam->H * cam->W), workspace_bytes);
+    // at least the tables; with the room nemo_solve_features_workspace names behind them, the first step's tiles are computed in bulk
+    if (m && m->bank_frag && n_img > 0 && cam) {
+        const size_t tables = align256((size_t)n_img * table_image_elems(m->V, cam->H * cam->W) * sizeof(float));
+        if (workspace_bytes < tables)
+            return fail(NEMO_ERR_INVALID, "nemo_solve_features: workspace of at least %zu bytes required (%zu with the lists of the first "
+                        "step's tiles), %zu given", tables, nemo_solve_features_workspace(m, n_img, cam->H * cam->W), workspace_bytes);
+    }
     return solve_impl(m, cam, feat, (float*)workspace, clu, hyp_to_image, init_campos, init_theta, init_principal, score_boxes, n_hyp, n_img,
-                      global_batch, dof, opt, out_pose, out_hist, hyp_to_part, stream);
+                      global_batch, dof, opt, out_pose, out_hist, hyp_to_part, stream, workspace_bytes);
 }
 
 // Refinement of the keypoint-initialised solver (solve_pose.py:220-324): every proposal of an image is one

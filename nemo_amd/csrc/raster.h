@@ -932,7 +932,9 @@ struct TileCtx {
     int nfb;                  // face blocks of the mesh (part): the face-block presence map's row length in bits
 };
 
-template <int NKS>
+// NA: channel steps of the bank's operand requested together (every request is a round trip to the L2: the loop, short of
+// registers, keeps two in flight; the kernel that computes the predicted tiles in bulk asks for more).
+template <int NKS, int NA_ = 2>
 __device__ inline void table_tiles_nks(const float* __restrict__ col, size_t HW, bool pok, const uint4* __restrict__ ap, size_t apiece,
                                        float4* __restrict__ out, float us, int g0, int vg_n, int nvb, const unsigned int* vbmask) {
     // the image's operand: all channel steps of the 32 pixels, both pieces, resident for the whole call (all of it
@@ -953,7 +955,7 @@ __device__ inline void table_tiles_nks(const float* __restrict__ col, size_t HW,
             split8(x[i], b[k0 + i]);
         }
     }
-    constexpr int NA = NKS < 2 ? NKS : 2;       // channel steps of the bank's operand in flight
+    constexpr int NA = NKS < NA_ ? NKS : NA_;   // channel steps of the bank's operand in flight
     for (int w = 0; w * 32 < nvb; ++w) {
         unsigned int todo = (unsigned)__builtin_amdgcn_readfirstlane((int)vbmask[w]);
         while (todo) {
@@ -1070,12 +1072,21 @@ __device__ inline void build_face_block_masks(const RasterCtx& rc, const Lds& s,
 //
 // A function of its own (not inlined), with every operand passed by value: the pass then leaves the register
 // allocation of the optimisation loop as it is without it.
+//
+// COLLECT: nothing is computed; the vertex blocks a pixel tile lacks are recorded in `need` (global memory, one row of
+// mw words per 32-pixel tile of this hypothesis) for the kernel that computes the first step's tiles in bulk
+// (tile_bulk_kernel).  (dx, dy): the entries are taken as if they covered the pixel that many columns / rows away (entries
+// that leave the map are skipped): called once per displacement of a small ring, this also lists the tiles the following
+// steps are likely to read, as faces move by fractions of a pixel per step.  Displaced pixels may lie in another wave's
+// chunks, so the presence words are updated atomically.
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
+template <bool COLLECT = false>
 __device__ inline void ensure_table_tiles_call(lds_u32* zkey, lds_u32* present, lds_u32* present_fb, lds_u32* fbmask,
                                                                   lds_u32* wmask, int W, int waves, int mw, int nfb, int first_chunk, int cnt,
                                                                   const float* feat, const uint4* bank, float* table, int HW, int nks, int vg_n,
-                                                                  size_t apiece, float unscale, int vb_first, int nvb) {
+                                                                  size_t apiece, float unscale, int vb_first, int nvb,
+                                                                  unsigned int* need = nullptr, int H = 0, int dx = 0, int dy = 0) {
     constexpr unsigned int kNone = 0xFFFFFFFFu;
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
@@ -1090,10 +1101,15 @@ __device__ inline void ensure_table_tiles_call(lds_u32* zkey, lds_u32* present, 
         bool miss = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = ib0 + lane + 64 * u < cnt;
+            bool ok = ib0 + lane + 64 * u < cnt;
             const unsigned int e = *(ok ? slot + u * slot_step : first);    // unconditional read; a lane past the end ...
             int px, py, f;
             unpack_entry(ok ? e : 0u, &px, &py, &f);                        // ... looks at pixel 0 / face 0 and reports nothing
+            if (COLLECT) {
+                px += dx; py += dy;
+                ok = ok && px >= 0 && px < W && py >= 0 && py < H;
+                if (!ok) { px = 0; py = 0; }
+            }
             const unsigned int pt = (unsigned)(py * W + px) >> 5, fb = (unsigned)f >> kFaceBlockShift;
             const unsigned int bit = pt * (unsigned)nfb + fb;
             const bool absent = ok && !((present_fb[bit >> 5] >> (bit & 31u)) & 1u);
@@ -1122,13 +1138,20 @@ __device__ inline void ensure_table_tiles_call(lds_u32* zkey, lds_u32* present, 
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             bool some = false;
             for (int w = lane; w < mw; w += 64) {
-                const unsigned int have = present[pt * mw + w], need = wmask[w] & ~have;
-                present[pt * mw + w] = have | need;
-                wmask[w] = need;
-                some |= need != 0u;
+                unsigned int have;
+                if (COLLECT) have = __hip_atomic_fetch_or(&present[pt * mw + w], wmask[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else { have = present[pt * mw + w]; present[pt * mw + w] = have | wmask[w]; }
+                const unsigned int lack = wmask[w] & ~have;
+                wmask[w] = lack;
+                some |= lack != 0u;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (__any(some)) {
+            if (COLLECT) {
+                for (int w = lane; w < mw; w += 64) {
+                    const unsigned int nd = wmask[w];
+                    if (nd) atomicOr(&need[pt * mw + w], nd);
+                }
+            } else if (__any(some)) {
                 table_tiles(feat, bank, table, HW, nks, vg_n, apiece, unscale, vb_first, nvb, (int)pt, (const unsigned int*)wmask);
                 computed = true;
             }
@@ -1141,6 +1164,42 @@ __device__ inline void ensure_table_tiles(const RasterCtx& rc, const Lds& s, con
     ensure_table_tiles_call((lds_u32*)s.zkey, (lds_u32*)s.present, (lds_u32*)s.present_fb, (lds_u32*)s.fbmask, (lds_u32*)s.wmask, rc.cc.W,
                             rc.L.waves, rc.L.mask_words, tc.nfb, first_chunk, cnt, tc.feat, tc.bank, tc.table, tc.HW, tc.nks, tc.vg_n,
                             tc.apiece, tc.unscale, tc.vb_first, tc.nvb);
+}
+
+// The tiles the covered entries read, recorded instead of computed (see ensure_table_tiles_call<COLLECT>): at their own
+// pixels and, with ring > 0, at the eight pixels `ring` columns / rows away.
+__device__ inline void collect_table_tiles(const RasterCtx& rc, const Lds& s, const TileCtx& tc, int first_chunk, int cnt,
+                                           unsigned int* need, int ring) {
+    for (int k = 4; k < (ring > 0 ? 13 : 5); ++k) {      // k % 9 runs over a 3 x 3 pattern, its centre (4) first and once
+        const int j = k % 9, dx = (j % 3 - 1) * ring, dy = (j / 3 - 1) * ring;
+        ensure_table_tiles_call<true>((lds_u32*)s.zkey, (lds_u32*)s.present, (lds_u32*)s.present_fb, (lds_u32*)s.fbmask, (lds_u32*)s.wmask,
+                                      rc.cc.W, rc.L.waves, rc.L.mask_words, tc.nfb, first_chunk, cnt, tc.feat, tc.bank, tc.table, tc.HW,
+                                      tc.nks, tc.vg_n, tc.apiece, tc.unscale, tc.vb_first, tc.nvb, need, rc.cc.H, dx, dy);
+    }
+}
+
+// The loop starts from presence maps that already hold the tiles computed in bulk: `need` (one row of mw words per
+// 32-pixel tile) is the list tile_bulk_kernel worked from.  A (pixel tile, face block) bit is set where every vertex
+// block the face block uses is present.  Call after build_face_block_masks; ends with a barrier.
+__device__ inline void preset_table_tiles(const RasterCtx& rc, const Lds& s, const TileCtx& tc, const unsigned int* need, int npt32) {
+    const int mw = rc.L.mask_words, nfb = tc.nfb;
+    for (int i = threadIdx.x; i < npt32 * mw; i += blockDim.x) s.present[i] = need[i];
+    __syncthreads();
+    const int nbits = npt32 * nfb;
+    for (int wi = threadIdx.x; wi * 32 < nbits; wi += blockDim.x) {
+        unsigned int word = 0u;
+        for (int b = 0; b < 32 && wi * 32 + b < nbits; ++b) {
+            const int bit = wi * 32 + b, pt = bit / nfb, fb = bit - pt * nfb;
+            unsigned int lacks = 0u, uses = 0u;
+            for (int w = 0; w < mw; ++w) {
+                const unsigned int m = s.fbmask[fb * mw + w];
+                uses |= m; lacks |= m & ~s.present[pt * mw + w];
+            }
+            if (uses && !lacks) word |= 1u << b;
+        }
+        s.present_fb[wi] = word;
+    }
+    __syncthreads();
 }
 
 }  // namespace nemo

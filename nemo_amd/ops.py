@@ -483,10 +483,13 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
 
 def solve_from_features(mesh, cam, feature_map, clu, init_campos, init_theta, init_principal=None, hyp_to_image=None,
                         global_batch=None, dof=3, steps=300, lr=0.05, betas=(0.4, 0.6), eps=1e-8, lr_gamma=0.2, lr_every=None,
-                        history=False, score_boxes=None, hyp_to_part=None, workspace=None):
-    """solve() without a precomputed table: the kernel computes the table tiles its covered pixels need, when they first
-    need them (bit for bit the result of similarity_table + solve).  feature_map [n_img,C,H,W]; workspace: an optional
-    float32 tensor of table_shape(mesh, n_img, H * W) to reuse (it need not be initialised).
+                        history=False, score_boxes=None, hyp_to_part=None, workspace=None, bulk_first_step=True):
+    """solve() without a precomputed table: the table tiles the covered pixels need are computed when they first need
+    them (bit for bit the result of similarity_table + solve).  feature_map [n_img,C,H,W]; workspace: an optional uint8
+    tensor of solve_workspace_bytes(mesh, n_img, H * W) to reuse (it need not be initialised).  bulk_first_step: the
+    tiles of the first step (and of a small ring of pixels around it) are listed by a launch that only looks and
+    computed by one kernel in front of the loop, when the workspace has room for the lists (it has for up to two
+    hypotheses per image); False: the loop computes every tile itself (same results).
     -> (pose [n_hyp,8], loss_hist [n_hyp,steps] or None)."""
     lib = _lib.load()
     fm = f32c(feature_map)
@@ -520,7 +523,13 @@ def solve_from_features(mesh, cam, feature_map, clu, init_campos, init_theta, in
         if h2p.numel() != n_hyp:
             raise ValueError("hyp_to_part needs one entry per hypothesis")
     with torch.cuda.device(cp.device):
-        check(lib.nemo_solve_features(mesh.h, C.byref(cc), ptr(fm), ptr(workspace, torch.uint8), workspace.numel(), ptr(clu2), ptr(h2i, torch.int32),
+        ws_bytes = workspace.numel()
+        if not bulk_first_step:         # the library takes the lists' room from what lies behind the tables
+            n_tab = 1
+            for d_ in table_shape(mesh, n_img, H * W):
+                n_tab *= d_
+            ws_bytes = (4 * n_tab + 255) // 256 * 256
+        check(lib.nemo_solve_features(mesh.h, C.byref(cc), ptr(fm), ptr(workspace, torch.uint8), ws_bytes, ptr(clu2), ptr(h2i, torch.int32),
                                       ptr(h2p, torch.int32), ptr(cp), ptr(th), ptr(pr), ptr(boxes, torch.int32), n_hyp, n_img, gb,
                                       int(dof), C.byref(opt), ptr(out), ptr(hist), stream_ptr()), "nemo_solve_features")
     return out, hist
@@ -538,6 +547,12 @@ def workspace_tables(mesh, workspace, n_img, HW):
     for d in shape:
         n *= d
     return workspace[:4 * n].view(torch.float32).view(shape)
+
+
+def workspace_dense(mesh, workspace, n_img, HW):
+    """The tables of a solve_from_features workspace as [n_img, V, HW] (a copy; entries of tiles that were never
+    computed hold whatever the workspace held)."""
+    return table_dense(workspace_tables(mesh, workspace, n_img, HW), mesh.V, HW)
 
 
 def on_demand_table_supported(mesh, cam=None, with_parts=False):

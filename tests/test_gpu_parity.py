@@ -528,9 +528,21 @@ def test_on_demand_table_equals_complete_table(which, B, spread, dof, request):
     work.fill_(float("nan"))                                  # stale contents must never matter
     pose, hist = ops.solve_from_features(sc.mod.mesh, cam, fm, clu, C0, th0, pr0, workspace=ws, **kw)
     assert torch.equal(pose, dense) and torch.equal(hist, dense_hist)
-    filled = ~torch.isnan(work)
+    # (compared as [image, vertex, pixel])
+    HWs = sc.H * sc.W
+    tab_d = ops.table_dense(tab, sc.mod.mesh.V, HWs)
+    work_d = ops.workspace_dense(sc.mod.mesh, ws, B, HWs)
+    filled = ~torch.isnan(work_d)
     frac = float(filled.float().mean())
-    assert torch.equal(work[filled], tab[filled]) and 0.005 < frac < 0.5, frac
+    assert torch.equal(work_d[filled], tab_d[filled]) and 0.005 < frac < 0.6, frac
+    # the same with every tile computed inside the loop (no launch that looks, no bulk kernel): equal results, and no
+    # tile that the bulk form did not also compute
+    work.fill_(float("nan"))
+    pose_l, hist_l = ops.solve_from_features(sc.mod.mesh, cam, fm, clu, C0, th0, pr0, workspace=ws, bulk_first_step=False, **kw)
+    assert torch.equal(pose_l, dense) and torch.equal(hist_l, dense_hist)
+    work_d = ops.workspace_dense(sc.mod.mesh, ws, B, HWs)
+    filled_l = ~torch.isnan(work_d)
+    assert torch.equal(work_d[filled_l], tab_d[filled_l]) and bool((filled | ~filled_l).all()) and int(filled_l.sum()) <= int(filled.sum())
     # four hypotheses per image on a shared workspace (tiles written by several workgroups, identical values)
     n = min(B, 8)
     h2i = torch.arange(n, dtype=torch.int32).repeat_interleave(4)
@@ -544,8 +556,9 @@ def test_on_demand_table_equals_complete_table(which, B, spread, dof, request):
     work4.fill_(float("nan"))
     got4, _ = ops.solve_from_features(sc.mod.mesh, cam, fm[:n], clu[:n], C4, th4, workspace=ws, **kw4)
     assert torch.equal(got4, ref4)
-    filled = ~torch.isnan(work4)
-    assert torch.equal(work4[filled], tab[:n][filled])
+    work_d = ops.workspace_dense(sc.mod.mesh, ws, n, HWs)
+    filled = ~torch.isnan(work_d)
+    assert torch.equal(work_d[filled], tab_d[:n][filled])
 
 
 def test_on_demand_table_channel_counts(gpu):
