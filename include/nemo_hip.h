@@ -104,6 +104,14 @@ int nemo_render(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, c
                 const float* principal, int32_t n, float* out_maps, int32_t* out_pix_to_face,
                 float* out_bary, float* out_zbuf, void* stream);
 
+/* forward_interpolate with mode='nearest' (nemo/utils/mesh.py:59-70,104-109): the same rasterisation, but a covered
+ * pixel takes the feature of the face's vertex with the largest barycentric coordinate (the first one on ties, as
+ * argmax picks it) instead of the barycentric blend.  Forward only: the reference's backward of this mode is a
+ * straight-through softmax over the barycentrics, which nothing on the solver path uses.  The reference forms the
+ * weight of that vertex as softmax + (1 - softmax) in f32, which is 1 or 1 - 2^-24; here it is exactly 1. */
+int nemo_render_nearest(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
+                        const float* principal, int32_t n, float* out_maps, void* stream);
+
 /* Backward of nemo_render's out_maps w.r.t. the camera, for callers that differentiate
  * MeshInterpolateModule.forward themselves (what torch autograd does through PyTorch3D in the
  * reference).  grad_maps [n,C,H,W] -> grad_campos [n,3], grad_theta [n], grad_principal [n,2]

@@ -428,6 +428,7 @@ struct RenderArgs {
     const float* campos; const float* theta; const float* principal;
     float def_px, def_py;
     float* out_maps; int32_t* out_p2f; float* out_bary; float* out_zbuf;
+    int nearest;             // out_maps takes the feature of the face's vertex with the largest barycentric (mode='nearest')
 };
 
 template <bool FL>
@@ -465,7 +466,11 @@ __global__ __launch_bounds__(kRasterThreads) void render_kernel(RenderArgs a) {
         }
         if (a.out_maps) {
             float* om = a.out_maps + (size_t)n * a.C * HW + p;
-            if (f >= 0) {
+            if (f >= 0 && a.nearest) {
+                // the first of the largest barycentrics, as argmax over the last axis picks it
+                const int iv = b[0] >= b[1] ? (b[0] >= b[2] ? i0 : i2) : (b[1] >= b[2] ? i1 : i2);
+                for (int c = 0; c < a.C; ++c) om[(size_t)c * HW] = a.memory_t[(size_t)c * V + iv];
+            } else if (f >= 0) {
                 for (int c = 0; c < a.C; ++c) {
                     const float* mt = a.memory_t + (size_t)c * V;
                     om[(size_t)c * HW] = (b[0] * mt[i0] + b[1] * mt[i1]) + b[2] * mt[i2];
@@ -483,9 +488,9 @@ static int set_lds_limit(K kernel, int bytes) {
     return NEMO_OK;
 }
 
-extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
-                           const float* principal, int32_t n, float* out_maps, int32_t* out_p2f, float* out_bary,
-                           float* out_zbuf, void* stream) {
+static int render_impl(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                       const float* principal, int32_t n, float* out_maps, int32_t* out_p2f, float* out_bary,
+                       float* out_zbuf, int nearest, void* stream) {
     if (n == 0) return NEMO_OK;
     if (!m || !campos || !theta || n < 0) return fail(NEMO_ERR_INVALID, "nemo_render: bad argument");
     if (check_cam(cam)) return NEMO_ERR_INVALID;
@@ -499,11 +504,24 @@ extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* c
     a.memory_t = m->memory_t; a.C = m->C;
     a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
     a.out_maps = out_maps; a.out_p2f = out_p2f; a.out_bary = out_bary; a.out_zbuf = out_zbuf;
+    a.nearest = nearest;
     auto kern = a.rc.L.faces >= 0 ? render_kernel<true> : render_kernel<false>;
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
+}
+
+extern "C" int nemo_render(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                           const float* principal, int32_t n, float* out_maps, int32_t* out_p2f, float* out_bary,
+                           float* out_zbuf, void* stream) {
+    return render_impl(m, cam, campos, theta, principal, n, out_maps, out_p2f, out_bary, out_zbuf, 0, stream);
+}
+
+extern "C" int nemo_render_nearest(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                   const float* principal, int32_t n, float* out_maps, void* stream) {
+    if (!out_maps) return fail(NEMO_ERR_INVALID, "nemo_render_nearest: out_maps is required");
+    return render_impl(m, cam, campos, theta, principal, n, out_maps, nullptr, nullptr, nullptr, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ Several meshes at once (lists of vertices / faces / memory banks, reference :110
 camera i renders mesh i (or the one camera renders every mesh); each mesh has its own handle and launch.
 
 Not supported (raise): the VoGE variant (needs the un-vendored VoGE package), blur_radius > 0,
-faces_per_pixel > 1, mode='nearest', off_set_mesh / deform_verts.
+faces_per_pixel > 1, the backward of mode='nearest', off_set_mesh / deform_verts.
 """
 import torch
 import torch.nn as nn
@@ -152,10 +152,15 @@ class MeshInterpolateModuleMesh(nn.Module):
             raise RuntimeError("call .to(device) / .cuda() first: MeshInterpolateModule renders on the GPU only")
         if blur_radius not in (0, 0.0):
             raise NotImplementedError("blur_radius > 0 is not supported")
-        if mode != "bilinear":
-            raise NotImplementedError("only mode='bilinear' is supported")
+        if mode not in ("bilinear", "nearest"):
+            raise ValueError(f"unknown interpolation mode {mode!r}")
         if deform_verts is not None:
             raise NotImplementedError("deform_verts is not supported")
+        if mode == "nearest":       # forward only (nemo/utils/mesh.py:59-70)
+            if torch.is_grad_enabled() and (campos.requires_grad or theta.requires_grad or (principal is not None and principal.requires_grad)):
+                raise NotImplementedError("mode='nearest' is forward only here: render under torch.no_grad() or with detached poses")
+            return ops.render(self.mesh, self.camera(), campos.detach(), theta.detach(),
+                              None if principal is None else principal.detach(), maps=True, nearest=True)["maps"]
         needs_grad = torch.is_grad_enabled() and (campos.requires_grad or theta.requires_grad or (
             principal is not None and principal.requires_grad))
         if needs_grad:

@@ -152,12 +152,22 @@ def project_keypoints(mesh, cam, campos, theta, principal=None, dist_thr=1e-3, r
     return kp, vis.bool()
 
 
-def render(mesh, cam, campos, theta, principal=None, maps=True, fragments=False):
-    """-> dict(maps [n,C,H,W], pix_to_face [n,H,W] i32, bary [n,H,W,3], zbuf [n,H,W]) (requested keys)."""
+def render(mesh, cam, campos, theta, principal=None, maps=True, fragments=False, nearest=False):
+    """-> dict(maps [n,C,H,W], pix_to_face [n,H,W] i32, bary [n,H,W,3], zbuf [n,H,W]) (requested keys).
+    nearest: the maps take the feature of the nearest vertex of the covering face (mode='nearest') instead of the blend."""
     lib = _lib.load()
     cp, th, pr, n = _pose_args(campos, theta, principal)
     dev = cp.device
     out = {}
+    if nearest:
+        if fragments or not maps:
+            raise ValueError("nearest=True renders maps only")
+        out["maps"] = torch.empty(n, mesh.C, cam.H, cam.W, device=dev)
+        cc = cam.c()
+        with torch.cuda.device(dev):
+            check(lib.nemo_render_nearest(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, ptr(out["maps"]), stream_ptr()),
+                  "nemo_render_nearest")
+        return out
     if maps:
         out["maps"] = torch.empty(n, mesh.C, cam.H, cam.W, device=dev)
     if fragments:

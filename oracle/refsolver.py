@@ -384,6 +384,17 @@ def interpolate_face_attributes(p2f, bary, face_memory):
     return torch.where((p2f >= 0)[..., None], out, torch.zeros(()))
 
 
+def set_bary_coords_to_nearest(bary):
+    """nemo/utils/mesh.py:59-70: one-hot of the largest barycentric, formed as softmax + (one_hot - softmax), plus the
+    negative parts of the input (the background's -1, which interpolate_face_attributes masks anyway)."""
+    shape = bary.shape
+    exr = bary * (bary < 0)
+    flat = bary.reshape(-1, shape[-1])
+    target = torch.zeros_like(flat).scatter(1, flat.argmax(1).unsqueeze(1), 1.0)
+    soft = torch.softmax(flat, dim=1)
+    return (soft + (target - soft)).view(*shape) + exr
+
+
 class MeshInterpolateModuleRef:
     """nemo/models/mesh_interpolate_module.py:92-217 (single mesh, blur 0, faces_per_pixel 1)."""
 
@@ -403,8 +414,10 @@ class MeshInterpolateModuleRef:
             pr = pr.expand(campos.shape[0], -1)
         return fragments(self.verts, self.faces, campos, theta, self.cam, pr)
 
-    def __call__(self, campos, theta):
+    def __call__(self, campos, theta, mode="bilinear"):
         p2f, bary, _ = self.fragments(campos, theta)
+        if mode == "nearest":
+            bary = set_bary_coords_to_nearest(bary)
         return interpolate_face_attributes(p2f, bary, self.face_memory).permute(0, 3, 1, 2)
 
 

@@ -127,6 +127,25 @@ def test_largest_maps_and_size_limits(gpu):
             ops.project_keypoints(big.mod.mesh, cam, campos[:1].to(gpu), theta[:1].to(gpu))
 
 
+def test_nearest_vertex_interpolation(small):
+    """mode='nearest' of forward_interpolate (nemo/utils/mesh.py:59-70,104-109): every covered pixel carries the
+    feature of the covering face's vertex with the largest barycentric; background zero.  Against the oracle's
+    restatement (softmax + (one_hot - softmax) weights, which are 1 or 1 - 2^-24) and against the vertex bank itself."""
+    sc = small
+    campos, theta = random_poses(5, seed=21, dist=(4.0, 6.0))
+    want = sc.ref(campos, theta, mode="nearest")
+    got = sc.mod(campos.to(sc.device), theta.to(sc.device), mode="nearest").cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 1e-6
+    p2f, bary, _ = R.fragments(sc.ref.verts, sc.ref.faces, campos, theta, sc.cam)
+    cov = p2f >= 0
+    assert cov.float().mean() > 0.02
+    vert = sc.ref.faces.long()[p2f.clamp(min=0)].gather(-1, bary.argmax(-1, keepdim=True)).squeeze(-1)      # [n,H,W]
+    exact = torch.where(cov[..., None], sc.mem[vert], torch.zeros(())).permute(0, 3, 1, 2)
+    assert torch.equal(got, exact), "a covered pixel does not hold exactly its nearest vertex's feature"
+    blend = sc.mod(campos.to(sc.device), theta.to(sc.device)).cpu()
+    assert not torch.equal(blend, got)
+
+
 def test_module_with_several_meshes(small):
     """A module holding several meshes: camera i renders mesh i (one camera renders every mesh); each map equals
     the single-mesh module's, which is held to the oracle; gradients reach the poses of every mesh."""
