@@ -389,10 +389,12 @@ def main():
         traffic = valu = grid_mfma_busy = None
         import glob
         counters, exact = None, False
-        for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_solve_counters*.json"))):
+        for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_solve_counters*.json")), reverse=True):
             with open(cpath) as fh:
                 cj = json.load(fh)
             if cj.get("adam_steps") != EPOCHS or cj.get("on_demand_table") != (not args.complete_table):
+                continue
+            if not args.complete_table and bool(cj.get("tile_bulk")) != (not args.no_bulk_tiles):
                 continue
             if cj.get("hypotheses_per_launch") == n_hyp:
                 counters, exact, csrc = cj, True, os.path.relpath(cpath, ROOT)
@@ -403,11 +405,14 @@ def main():
             # the same kernel on the same scene does the same work per hypothesis: a profile of another launch size is scaled
             cj, scale = counters, n_hyp / counters["hypotheses_per_launch"]
             how = "" if exact else f", scaled from a launch of {cj['hypotheses_per_launch']} hypotheses"
-            traffic = (cj["fetch_size_kb_per_launch"] + cj["write_size_kb_per_launch"]) * 1024.0 * scale
+            # the solve call = the loop and, with the first step's tiles in bulk, the launch that lists them and the kernel that computes them
+            calls = [cj] + [cj[k] for k in ("footprint", "tile_bulk") if cj.get(k) and not args.no_bulk_tiles]
+            traffic = sum(c_["fetch_size_kb_per_launch"] + c_["write_size_kb_per_launch"] for c_ in calls) * 1024.0 * scale
+            insts = sum(c_["sq_insts_valu_per_launch"] for c_ in calls) * scale
             # vector issue: a SIMD issues one wave-instruction per 2 cycles (64 lanes over a 32-wide unit)
             peak_issue = cj["compute_units"] * 4 * cj["shader_clock_ghz"] * 1e9 / 2
-            valu = {"wave_instructions_per_launch": cj["sq_insts_valu_per_launch"] * scale, "peak_per_sec": peak_issue,
-                    "frac": cj["sq_insts_valu_per_launch"] * scale / (solve_ms * 1e-3) / peak_issue,
+            valu = {"wave_instructions_per_launch": insts, "peak_per_sec": peak_issue,
+                    "frac": insts / (solve_ms * 1e-3) / peak_issue,
                     "model": f"{cj['compute_units']} CUs x 4 SIMDs x {cj['shader_clock_ghz']} GHz / 2 cycles per wave-instruction",
                     "source": f"{csrc} (rocprofv3 --pmc SQ_INSTS_VALU{how})"}
             traffic_source = f"{csrc} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, bytes per launch{how})"
@@ -461,7 +466,9 @@ def main():
                                     (" (process group: " + dist.get_backend() + ")" if grouped else "")},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": n_hyp,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
-            "roofline": {"kernel": "solve_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "solve_kernel" if args.complete_table or args.no_bulk_tiles else
+                                   "solve_kernel (the solve call: the loop, the launch that lists its first step's tiles and tile_bulk_kernel)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": solve_algo,
                          "census": {"covered_pixels_per_step": covered, "table_tiles_computed": tiles, "pixel_tiles_touched": pixel_tiles,

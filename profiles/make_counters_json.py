@@ -47,6 +47,17 @@ def main(d, tag, out, n_hyp=512):
         return float(r["AveragePerDispatch"]) / float(stats[k]["AverageNs"])
 
     solve, mfma = kern("solve_kernel"), kern("grid_mfma_kernel")
+
+    def helper(sub, exclude=None):
+        """A launch that belongs to the solve call besides the loop (the launch that lists the first step's tiles, the
+        kernel that computes them): duration and counters per launch, or None when the run had none."""
+        names = [k for k in stats if sub in k and k != exclude]
+        if not names:
+            return None
+        k = min(names, key=lambda n: float(stats[n]["TotalDurationNs"])) if sub == "solve_kernel" else names[0]
+        return {"kernel": k, "avg_duration_ms": float(stats[k]["AverageNs"]) / 1e6,
+                "fetch_size_kb_per_launch": per_launch(k, "FETCH_SIZE"), "write_size_kb_per_launch": per_launch(k, "WRITE_SIZE"),
+                "sq_insts_valu_per_launch": per_launch(k, "SQ_INSTS_VALU")}
     res = {
         "tag": tag,
         "command": "bash profiles/collect.sh (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE | WRITE_SIZE | SQ_* | MFMA counters, one run each, "
@@ -67,6 +78,7 @@ def main(d, tag, out, n_hyp=512):
         "note": "FETCH_SIZE / WRITE_SIZE are KB of fabric-side L2 requests (Infinity-Cache hits included); the gfx950 x2 correction of FETCH_SIZE "
                 "applies to wide streaming reads, this kernel mostly gathers single 16-byte table elements, so the raw value is kept. The writes "
                 "are the computed table tiles, the register spills (scratch) and the results.",
+        "footprint": helper("solve_kernel", exclude=solve), "tile_bulk": helper("tile_bulk_kernel"),
         "grid_mfma": {
             "kernel": mfma, "images_per_launch": n_hyp, "avg_duration_ms": float(stats[mfma]["AverageNs"]) / 1e6,
             "shader_clock_ghz": round(clock_ghz(mfma), 3),
