@@ -328,6 +328,16 @@ int nemo_solve_features(nemo_mesh_t mesh, const nemo_camera* cam, const float* f
                         const int32_t* score_boxes, int32_t n_hyp, int32_t n_img, int32_t global_batch, int32_t dof,
                         const nemo_adam* opt, float* out_pose, float* out_loss_hist, void* stream);
 
+/* Diagnostic (no counterpart in the reference): the rasterise phase of the optimisation loop in two forms on the same
+ * poses, timed in shader cycles inside the kernel.  form 0 = the form the solver uses (a face per lane walks the pixel
+ * centres of its bounding box, LDS atomic min on depth | face keys); form 1 = faces binned to 8 x 8-pixel tiles in LDS,
+ * a wave per tile, lanes = pixels, no atomics on the keys.  One workgroup per pose, `reps` rasterisations each.
+ * out_cycles [2 n]: per pose the average cycles of one rasterisation, then (form 1) of its binning part;
+ * out_keys [n, H*W] u32 or NULL: the key buffer after the last one (0xFFFFFFFF = not covered, else quantised depth
+ * above the face index). */
+int nemo_raster_forms(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta, int32_t n,
+                      int32_t form, int32_t reps, float* out_cycles, uint32_t* out_keys, void* stream);
+
 /* camera_position_to_spherical_angle (nemo/utils/mesh.py:50-56) on device:
  * campos [n,3] -> out [n,3] = distance, elevation, azimuth. */
 int nemo_spherical_angles(const float* campos, int32_t n, float* out, void* stream);

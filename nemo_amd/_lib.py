@@ -20,7 +20,7 @@ SYMBOLS = [
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_clutter_grid_score_packed", "nemo_grid_fragments_bytes", "nemo_grid_score_fragments_workspace", "nemo_grid_score_fragments", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
     "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
-    "nemo_solve_features_workspace", "nemo_solve_features_supported", "nemo_solve_features", "nemo_render_nearest",
+    "nemo_solve_features_workspace", "nemo_solve_features_supported", "nemo_solve_features", "nemo_render_nearest", "nemo_raster_forms",
     "nemo_project_keypoints", "nemo_gather_features", "nemo_gather_features_backward", "nemo_gather_idx", "nemo_mask_weight",
 ]
 
@@ -95,6 +95,7 @@ def load():
     lib.nemo_project_keypoints.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, f32p, i32, C.c_float, i32, f32p, vp, vp]
     lib.nemo_solve_features_supported.argtypes = [vp, i32, i32, i32]
     lib.nemo_render_nearest.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, f32p, vp]
+    lib.nemo_raster_forms.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, i32, i32, i32, f32p, vp, vp]
     lib.nemo_solve_features_workspace.argtypes = [vp, i32, i32]
     lib.nemo_solve_features_workspace.restype = C.c_size_t
     lib.nemo_solve_features.argtypes = [vp, C.POINTER(NemoCamera), f32p, vp, C.c_size_t, f32p, vp, vp, f32p, f32p, f32p, vp, i32, i32,

@@ -1490,6 +1490,87 @@ __global__ __launch_bounds__(64 * kBulkWaves) void tile_bulk_kernel(SolveArgs a,
     table_tiles_nks<NKS, (NKS < 4 ? NKS : 4)>(col, HW, pok, ap, a.apiece, out, a.meta->unscale, g0, vg_n, nvb, nm);
 }
 
+// Diagnostic: the rasterise phase of the optimisation loop in its two forms on the same poses, timed in shader cycles.
+// form 0: raster_direct (face per lane, bounding-box walk, LDS atomic min); form 1: raster_tiled (faces binned to 8 x 8
+// tiles, a wave per tile, lanes = pixels).  One workgroup per pose, `reps` rasterisations each; out_cycles[pose] = average
+// cycles of one (for form 1, out_cycles[n + pose] = the binning part of it); out_keys [n, HW] = the key buffer of the last.
+struct RasterFormsArgs {
+    RasterCtx rc; const float* campos; const float* theta; float def_px, def_py;
+    int form, reps, bins_off, bins_cap;
+    float* out_cycles; unsigned int* out_keys; int n;
+};
+template <bool FL>
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_forms_kernel(RasterFormsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds s = carve(smem, a.rc.L);
+    const RasterCtx& rc = a.rc;
+    const int h = blockIdx.x, tid = threadIdx.x, H = rc.cc.H, W = rc.cc.W, HW = H * W;
+    solve_prologue(rc, s);
+    const int TX = (W + 7) >> kBinShift, TY = (H + 7) >> kBinShift, NT = TX * TY;
+    TileBins tb;
+    tb.cnt = (unsigned int*)(smem + a.bins_off); tb.cur = tb.cnt + NT + 1; tb.ent = (unsigned short*)(tb.cur + NT); tb.cap = a.bins_cap;
+    if (tid == 0) {
+        float P[3] = {a.campos[3 * h], a.campos[3 * h + 1], a.campos[3 * h + 2]};
+        pose_setup<false>(rc.cc, P, a.theta[h], a.def_px, a.def_py, s.pc);
+        bool outside = false;
+        for (int k = 0; k < 3; ++k) {
+            const float m = 1e-3f * (rc.aabb[3 + k] - rc.aabb[k]) + 1e-6f;
+            outside = outside | (P[k] < rc.aabb[k] - m) | (P[k] > rc.aabb[3 + k] + m);
+        }
+        s.pc->cull = rc.outward && outside;
+        const float z0 = s.pc->T[2] - rc.depth_margin;
+        s.pc->qz0 = z0; s.pc->qc = 8388608.0f - z0 * rc.depth_scale;
+        s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u;
+    }
+    __syncthreads();
+    project_vertices(rc, s);
+    long long total = 0, binning = 0;
+    for (int rep = 0; rep < a.reps; ++rep) {
+        const long long t0 = clock64();
+        long long tb_end = t0;
+        if (a.form == 0) raster_direct<FL>(rc, s); else raster_tiled<FL>(rc, s, tb, &tb_end);
+        const long long t1 = clock64();
+        total += t1 - t0; binning += tb_end - t0;
+        if (rep == a.reps - 1 && a.out_keys)
+            for (int p = tid; p < HW; p += blockDim.x) a.out_keys[(size_t)h * HW + p] = s.zkey[p];
+        __syncthreads();
+        for (int p = tid; p < HW; p += blockDim.x) s.zkey[p] = kEmptyKey32;
+        if (tid == 0) { s.qcount[0] = (unsigned)H; s.qcount[1] = 0u; s.qcount[2] = kSolveThreads / 64; s.qcount[3] = 0u; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.out_cycles[h] = (float)total / (float)a.reps;
+        a.out_cycles[a.n + h] = (float)binning / (float)a.reps;
+    }
+}
+
+extern "C" int nemo_raster_forms(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta, int32_t n,
+                                 int32_t form, int32_t reps, float* out_cycles, uint32_t* out_keys, void* stream) {
+    if (!m || !campos || !theta || !out_cycles || n <= 0 || reps <= 0 || (form != 0 && form != 1))
+        return fail(NEMO_ERR_INVALID, "nemo_raster_forms: bad argument");
+    if (check_cam(cam)) return NEMO_ERR_INVALID;
+    if (m->F >= (1 << 16)) return fail(NEMO_ERR_UNSUPPORTED, "nemo_raster_forms: meshes below 65536 faces");
+    RasterFormsArgs a;
+    a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
+    a.rc.outward = m->faces_outward != nullptr;
+    for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
+    a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
+    int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
+    if (rcode) return rcode;
+    const int NT = ((cam->W + 7) >> nemo::kBinShift) * ((cam->H + 7) >> nemo::kBinShift);
+    a.bins_off = a.rc.L.total;
+    a.bins_cap = 4096;
+    const int lds = a.bins_off + 4 * (2 * NT + 1) + 2 * a.bins_cap;
+    if (lds > kMaxLds) return fail(NEMO_ERR_UNSUPPORTED, "nemo_raster_forms: %d bytes of LDS", lds);
+    a.campos = campos; a.theta = theta; a.def_px = cam->px; a.def_py = cam->py;
+    a.form = form; a.reps = reps; a.out_cycles = out_cycles; a.out_keys = out_keys; a.n = n;
+    auto kern = a.rc.L.faces >= 0 ? raster_forms_kernel<true> : raster_forms_kernel<false>;
+    if (set_lds_limit(kern, lds)) return NEMO_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(n), dim3(kSolveThreads), lds, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
 // The sizes the optimisation loop's LDS plan is made for: the whole handle, or its largest part.
 static void solve_plan_sizes(const nemo_mesh_s* m, bool use_parts, int* lay_v, int* lay_f, int* lay_blocks) {
     *lay_v = m->V; *lay_f = m->F; *lay_blocks = ((m->V - 1) >> 5) + 1;

@@ -812,6 +812,103 @@ __device__ inline void raster_direct(const RasterCtx& rc, const Lds& s) {
     }
     __syncthreads();
 }
+
+// ---- the tile-binned form of the same rasteriser (diagnostic: nemo_raster_forms) -----------------------------------
+// Faces binned to 8 x 8-pixel tiles in LDS, then a wave per tile with lanes = the tile's 64 pixels and one loop trip per
+// face of the tile's bin: the shape that suits triangles of tens of pixels.  A lane owns its pixel, so the depth test
+// runs in a register and the key buffer is written with plain stores (no atomics); against that, every (face, tile)
+// pair repeats the face's whole set-up on all 64 lanes.  The reference's meshes project to 2 - 3 pixel centres per
+// face, where the face-per-lane walk above wins by a wide margin; this form is kept to measure that (it is not used by
+// the solver).  Same arithmetic per (face, pixel) as walk_setup / walk_step except that the edge functions are
+// evaluated at the pixel instead of stepped to it, so a centre within rounding distance of an edge may differ.
+struct TileBins {
+    unsigned int* cnt;      // [tiles + 1]: faces per tile, then (after the scan) the first entry of every tile
+    unsigned int* cur;      // [tiles]: fill cursors
+    unsigned short* ent;    // [cap]: face indices, tile by tile
+    int cap;
+};
+constexpr int kBinShift = 3;       // 8 x 8 pixels
+
+template <bool FACES_LDS>
+__device__ inline void raster_tiled(const RasterCtx& rc, const Lds& s, const TileBins& tb, long long* t_bin) {
+    WalkGrid g;
+    g.H = rc.cc.H; g.W = rc.cc.W;
+    const float rx = ndc_range(g.W, g.H), ry = ndc_range(g.H, g.W);
+    g.dx = rx / (float)g.W; g.dy = ry / (float)g.H;
+    g.x_org = -0.5f * rx + 0.5f * g.dx; g.y_org = -0.5f * ry + 0.5f * g.dy;
+    g.inv_dx = (float)g.W / rx; g.inv_dy = (float)g.H / ry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const bool cull = s.pc->cull != 0;
+    const float qc = s.pc->qc;
+    const int face_bits = rc.face_bits;
+    const int TX = (g.W + 7) >> kBinShift, TY = (g.H + 7) >> kBinShift, NT = TX * TY;
+    for (int t = threadIdx.x; t <= NT; t += blockDim.x) tb.cnt[t] = 0u;
+    __syncthreads();
+    // pass 1 and 2 over the faces: count per tile, then fill.  A face's pixel box as in walk_setup.
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int f = threadIdx.x; f < rc.F; f += blockDim.x) {
+            int i0, i1, i2;
+            load_face2<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+            const FaceVerts fv = face_verts(s, i0, i1, i2);
+            WalkState w; int box[4];
+            const bool slow = walk_setup(g, f, true, cull, rc.depth_scale, fv, &w, box);
+            if (w.n <= 0 || slow) continue;
+            // box is in flipped indices j (pixel = side - 1 - j)
+            const int x0 = g.W - 1 - box[2], x1 = g.W - 1 - box[0], y0 = g.H - 1 - box[3], y1 = g.H - 1 - box[1];
+            for (int ty = y0 >> kBinShift; ty <= y1 >> kBinShift; ++ty)
+                for (int tx = x0 >> kBinShift; tx <= x1 >> kBinShift; ++tx) {
+                    const int t = ty * TX + tx;
+                    if (pass == 0) atomicAdd(&tb.cnt[t], 1u);
+                    else { const unsigned int slot = atomicAdd(&tb.cur[t], 1u); if ((int)slot < tb.cap) tb.ent[slot] = (unsigned short)f; }
+                }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x < 64) {           // exclusive scan of the NT counters by one wave: a run of consecutive tiles per lane
+                const int per = (NT + 63) >> 6, t0 = lane * per;
+                unsigned int c[4] = {0u, 0u, 0u, 0u};            // NT <= 256 (maps up to 128 x 128)
+                int sum = 0;
+                for (int k = 0; k < per; ++k) { c[k] = t0 + k < NT ? tb.cnt[t0 + k] : 0u; sum += (int)c[k]; }
+                int total;
+                unsigned int run = (unsigned int)(wave_inclusive_scan(sum, &total) - sum);
+                for (int k = 0; k < per; ++k)
+                    if (t0 + k < NT) { tb.cnt[t0 + k] = run; tb.cur[t0 + k] = run; run += c[k]; }
+                if (lane == 0) tb.cnt[NT] = (unsigned int)total;
+            }
+            __syncthreads();
+        }
+    }
+    if (t_bin) *t_bin = clock64();
+    // a wave per tile (tile t belongs to wave t mod waves), lanes = pixels
+    for (int t = wave; t < NT; t += nwaves) {
+        const unsigned int e0 = tb.cnt[t], e1 = min(tb.cnt[t + 1], (unsigned)tb.cap);
+        if (e1 <= e0) continue;
+        const int xi = (t % TX) * 8 + (lane & 7), yi = (t / TX) * 8 + (lane >> 3);
+        const bool inmap = xi < g.W && yi < g.H;
+        const float xo = (float)(g.W - 1 - xi) * g.dx + g.x_org, yo = (float)(g.H - 1 - yi) * g.dy + g.y_org;
+        unsigned int best = kEmptyKey32;
+#pragma unroll 4
+        for (unsigned int e = e0; e < e1; ++e) {      // (unrolled: the LDS reads of four faces are in flight together)
+            const int f = tb.ent[e];
+            int i0, i1, i2;
+            load_face2<FACES_LDS>(rc, s, f, &i0, &i1, &i2);
+            const FaceVerts fv = face_verts(s, i0, i1, i2);
+            const float A0 = fv.y2 - fv.y1, B0 = fv.x1 - fv.x2, A1 = fv.y0 - fv.y2, B1 = fv.x2 - fv.x0, A2 = fv.y1 - fv.y0, B2 = fv.x0 - fv.x1;
+            const float farea = A0 * (fv.x0 - fv.x1) + B0 * (fv.y0 - fv.y1);
+            const float sgn = farea < 0.0f ? -1.0f : 1.0f;
+            const float q0 = sgn * ((xo - fv.x1) * A0 + (yo - fv.y1) * B0), q1 = sgn * ((xo - fv.x2) * A1 + (yo - fv.y2) * B1),
+                        q2 = sgn * ((xo - fv.x0) * A2 + (yo - fv.y0) * B2);
+            const float z12 = fv.z1 * fv.z2, z02 = fv.z0 * fv.z2, z01 = fv.z0 * fv.z1;
+            const float su = q0 * z12 + q1 * z02 + q2 * z01;
+            const float numer = (fv.z0 * z12) * fabsf(farea) * rc.depth_scale;
+            const float tq = __builtin_fmaf(numer, __builtin_amdgcn_rcpf(su), qc);
+            const unsigned int key = (__float_as_uint(tq) << face_bits) | (unsigned int)f;
+            if (fminf(fminf(q0, q1), q2) > 0.0f) best = min(best, key);
+        }
+        if (inmap && best != kEmptyKey32) s.zkey[yi * g.W + xi] = best;
+    }
+    __syncthreads();
+}
 #pragma clang fp contract(off)
 
 // Evaluates n queued (face, pixel) pairs, kPairBatch per thread at a time so that the dependent LDS

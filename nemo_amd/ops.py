@@ -199,6 +199,20 @@ def render_backward(mesh, cam, campos, theta, principal, grad_maps, want_princip
     return gC, gT, gP
 
 
+def raster_forms(mesh, cam, campos, theta, form, reps=20, keys=True):
+    """Diagnostic: the optimisation loop's rasterise phase, form 0 (face per lane, the solver's) or 1 (tile-binned), timed
+    inside the kernel.  -> (cycles per rasterisation [n], cycles of the binning part [n] (form 1), key buffers [n,H,W] int64 or None)."""
+    lib = _lib.load()
+    cp, th, _, n = _pose_args(campos, theta, None)
+    cyc = torch.empty(2 * n, device=cp.device)
+    kb = torch.empty(n, cam.H, cam.W, dtype=torch.int32, device=cp.device) if keys else None
+    cc = cam.c()
+    with torch.cuda.device(cp.device):
+        check(lib.nemo_raster_forms(mesh.h, C.byref(cc), ptr(cp), ptr(th), n, int(form), int(reps), ptr(cyc), ptr(kb, torch.int32),
+                                    stream_ptr()), "nemo_raster_forms")
+    return cyc[:n], cyc[n:], (None if kb is None else kb.long() & 0xFFFFFFFF)
+
+
 def clutter_score(feature_map, clutter):
     """feature_map [B,C,H,W], clutter [K,C] -> [B,H,W] (max over the K clutter vectors)."""
     lib = _lib.load()

@@ -146,6 +146,31 @@ def test_nearest_vertex_interpolation(small):
     assert not torch.equal(blend, got)
 
 
+def test_raster_forms_agree(full):
+    """The optimisation loop's rasteriser in its two forms (ops.raster_forms: a face per lane walking its bounding box,
+    and faces binned to 8 x 8 tiles with a wave per tile) decides coverage and the winning face alike: they share the
+    arithmetic per (face, pixel) up to stepping an edge function against evaluating it in place, so a centre within
+    rounding distance of an edge may differ.  Against the bit-exact renderer's face-index buffer as well."""
+    from nemo_amd import ops
+    sc = full
+    campos, theta = random_poses(24, seed=31, dist=(4.5, 5.5))
+    cam = sc.mod.camera()
+    _, _, k0 = ops.raster_forms(sc.mod.mesh, cam, campos.to(sc.device), theta.to(sc.device), 0, reps=2)
+    _, _, k1 = ops.raster_forms(sc.mod.mesh, cam, campos.to(sc.device), theta.to(sc.device), 1, reps=2)
+    empty = 0xFFFFFFFF
+    fbits = 9
+    while (1 << fbits) <= sc.mod.mesh.F:
+        fbits += 1
+    cov0, cov1 = k0 != empty, k1 != empty
+    assert int(cov0.sum()) > 24 * 500
+    assert int((cov0 ^ cov1).sum()) <= 8
+    both = cov0 & cov1
+    f0, f1 = (k0 & ((1 << fbits) - 1))[both], (k1 & ((1 << fbits) - 1))[both]
+    assert int((f0 != f1).sum()) <= 8
+    p2f = ops.render(sc.mod.mesh, cam, campos.to(sc.device), theta.to(sc.device), maps=False, fragments=True)["pix_to_face"].long()
+    assert int(((p2f >= 0) ^ cov0).sum()) <= 8 and int((p2f[both] != f0).sum()) <= 8
+
+
 def test_module_with_several_meshes(small):
     """A module holding several meshes: camera i renders mesh i (one camera renders every mesh); each map equals
     the single-mesh module's, which is held to the oracle; gradients reach the poses of every mesh."""
