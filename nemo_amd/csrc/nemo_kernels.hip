@@ -1462,7 +1462,9 @@ constexpr int kBulkWaves = 4;
 constexpr int kBulkRing = 2;
 template <int NKS>
 __global__ __launch_bounds__(64 * kBulkWaves) void tile_bulk_kernel(SolveArgs a, int mw) {
-    const int h = blockIdx.y, pt = blockIdx.x * kBulkWaves + (threadIdx.x >> 6);
+    // one-dimensional grid, a hypothesis's groups of kBulkWaves pixel tiles side by side (neighbouring workgroups read neighbouring columns)
+    const int groups = (a.npt32 + kBulkWaves - 1) / kBulkWaves;
+    const int h = blockIdx.x / groups, pt = (blockIdx.x % groups) * kBulkWaves + (threadIdx.x >> 6);
     if (pt >= a.npt32) return;
     const unsigned int* nm = a.need + ((size_t)h * a.npt32 + pt) * mw;
     unsigned int any = 0u;
@@ -1653,7 +1655,9 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, 
             if (set_lds_limit(look, a.rc.L.total)) return NEMO_ERR_HIP;
             hipLaunchKernelGGL(look, dim3(n_hyp), dim3(kSolveThreads), a.rc.L.total, (hipStream_t)stream, a);
             HIP_TRY(hipGetLastError());
-            const dim3 bg((a.npt32 + kBulkWaves - 1) / kBulkWaves, n_hyp);
+            const long long nblk = (long long)n_hyp * ((a.npt32 + kBulkWaves - 1) / kBulkWaves);
+            if (nblk > 0x7FFFFFFFLL) return fail(NEMO_ERR_UNSUPPORTED, "nemo_solve_features: too many hypotheses for one call");
+            const dim3 bg((unsigned)nblk);
             const int mw = a.rc.L.mask_words;
             switch (a.nks) {
                 case 1: hipLaunchKernelGGL(tile_bulk_kernel<1>, bg, dim3(64 * kBulkWaves), 0, (hipStream_t)stream, a, mw); break;
