@@ -376,10 +376,12 @@ def main():
             tables[0][:n_img].fill_(float("nan"))
             one_group(G, gather=False)
             torch.cuda.synchronize()
-            filled = ~torch.isnan(tables[0][:n_img])             # [n_img, HW/128, V/4, 128, 4]
-            tiles = int(filled.sum()) // 1024
-            pixel_tiles = int(filled.any(dim=4).any(dim=2).view(n_img, -1, 4, 32).any(dim=3).sum())
-            del filled
+            tiles = pixel_tiles = 0
+            for i0 in range(0, n_img, 64):                       # (in slices: the masks of a whole group would take tens of GB)
+                filled = ~torch.isnan(tables[0][i0:min(i0 + 64, n_img)])      # [., HW/128, V/4, 128, 4]
+                tiles += int(filled.sum(dtype=torch.int64)) // 1024
+                pixel_tiles += int(filled.any(dim=4).any(dim=2).view(filled.shape[0], -1, 4, 32).any(dim=3).sum())
+                del filled
             bank_bytes = -(-v.shape[0] // 32) * 32 * C * 2 * 2   # two f16 pieces per value
             solve_algo += tiles * 4096 + pixel_tiles * C * 32 * 4 + bank_bytes
         solve_ms = kern_ms["solve"]
