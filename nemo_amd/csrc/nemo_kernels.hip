@@ -1325,12 +1325,14 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             vals[12] = gfx * a.inv_tscale; vals[13] = gfy * a.inv_tscale; vals[14] = dmax; vals[15] = dbox;
         } else {
         int first_chunk;
-        const int cnt = compact_covered32(rc, s, row0, row1, &first_chunk);
+        bool tile_missing = false;
+        const int cnt = (ONDEMAND && !FOOTPRINT) ? compact_covered32<true>(rc, s, row0, row1, &first_chunk, tc.nfb, &tile_missing)
+                                                 : compact_covered32(rc, s, row0, row1, &first_chunk);
         if (FOOTPRINT) {
             collect_table_tiles(rc, s, tc, first_chunk, cnt, a.need + (size_t)h * a.npt32 * rc.L.mask_words, a.dilate);
             return;
         }
-        if (ONDEMAND) ensure_table_tiles(rc, s, tc, first_chunk, cnt);
+        if (ONDEMAND && __any(tile_missing)) ensure_table_tiles(rc, s, tc, first_chunk, cnt);
 #ifdef NEMO_STAMPS_P1
         if ((tid & 63) == 0 && a.out_hist) atomicAdd(&a.out_hist[(size_t)h * a.steps + 13], (float)cnt / (float)a.steps);
 #endif

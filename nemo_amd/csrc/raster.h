@@ -1109,7 +1109,12 @@ __device__ __attribute__((noinline, cold)) void table_tiles(const float* feat, c
 // which it has already read: the key buffer doubles as the entry list and no other wave touches these chunks
 // before the next step.  The caller consumes the entries with the same slot arithmetic and leaves every slot
 // empty again.  Returns the number of entries; *first_chunk = the wave's first chunk.  No barrier.
-__device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int row0, int row1, int* first_chunk) {
+// DETECT (on-demand similarity table): while pixel and face of an entry are at hand, its (32-pixel tile, face block)
+// presence bit is tested too; *missing = some entry of this wave lacks a tile (the caller then runs ensure_table_tiles,
+// otherwise it has nothing to do: the common case after the first steps).
+template <bool DETECT = false>
+__device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int row0, int row1, int* first_chunk, int nfb = 0,
+                                        bool* missing = nullptr) {
     const int W = rc.cc.W, nw = rc.L.waves;
     const int c0 = (row0 * W) >> 6, c1 = (row1 * W + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1117,6 +1122,7 @@ __device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int r
     const float inv_w = 1.0f / (float)W;
     const int cw = c0 + ((wave - c0 % nw) + nw) % nw;       // first chunk >= c0 owned by this wave
     int count = 0;
+    bool absent_any = false;
     constexpr int CB = 4;                       // chunks in flight per wave: their key reads overlap
     for (int cb = cw; cb < c1; cb += CB * nw) {
         unsigned int key[CB];
@@ -1135,11 +1141,16 @@ __device__ inline int compact_covered32(const RasterCtx& rc, const Lds& s, int r
                 const int j = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                 const int yi = (int)(((float)p + 0.5f) * inv_w);       // exact for p < 2^22
                 s.zkey[(cw + (j >> 6) * nw) * 64 + (j & 63)] = pack_entry(p - yi * W, yi, (int)(key[u] & fmask));
+                if (DETECT) {
+                    const unsigned int bit = ((unsigned)p >> 5) * (unsigned)nfb + ((key[u] & fmask) >> kFaceBlockShift);
+                    absent_any |= !((s.present_fb[bit >> 5] >> (bit & 31u)) & 1u);
+                }
             }
             count += __popcll(m);
         }
     }
     *first_chunk = cw;
+    if (DETECT) *missing = absent_any;
     return count;
 }
 
