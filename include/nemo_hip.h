@@ -334,7 +334,8 @@ int nemo_solve_features(nemo_mesh_t mesh, const nemo_camera* cam, const float* f
  * a wave per tile, lanes = pixels, no atomics on the keys.  One workgroup per pose, `reps` rasterisations each.
  * out_cycles [2 n]: per pose the average cycles of one rasterisation, then (form 1) of its binning part;
  * out_keys [n, H*W] u32 or NULL: the key buffer after the last one (0xFFFFFFFF = not covered, else quantised depth
- * above the face index). */
+ * above the face index).  Form 1 keeps 4096 (face, tile) pairs per pose in LDS and drops the rest (the reference's
+ * meshes need about 1300); meshes of 65536 faces and more are refused. */
 int nemo_raster_forms(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta, int32_t n,
                       int32_t form, int32_t reps, float* out_cycles, uint32_t* out_keys, void* stream);
 
