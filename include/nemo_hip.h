@@ -156,7 +156,11 @@ int nemo_grid_score(const float* pre, const float* feat, const float* clu, int32
  * it runs on until the process ends; the call allocates and frees nothing.  Sizes whose partial sums
  * (nemo_grid_score_workspace(N, B, HW) bytes) exceed the array are refused with NEMO_ERR_UNSUPPORTED.  All
  * calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams or host
- * threads) race on it; calls that follow each other on one stream do not. */
+ * threads) race on it; calls that follow each other on one stream do not.
+ * The device that owns `stream` must be the current device (NEMO_ERR_STATE otherwise: each GPU holds its own copy
+ * of the array).  The first call on a device looks up the array's address there (the runtime may load the library's
+ * code object at that moment): make one ordinary, eager call per device before any call under graph capture or
+ * inside a serving loop; every later call only launches kernels. */
 #define NEMO_STATIC_SCRATCH_BYTES (16u << 20)
 int nemo_grid_score_static(const float* pre, const float* feat, const float* clu, int32_t N, int32_t B,
                            int32_t C, int32_t HW, float* out_loss, int32_t* out_argmin, float* out_min,

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void grid_feat_clutter_kernel(const float* __r
             const int pj = p0 + cpx + 8 * j;
             float best = acc[j][0];
 #pragma unroll
-            for (int k = 1; k < K; ++k) best = fmaxf(best, acc[j][k]);
+            for (int k = 1; k < K; ++k) best = max_nan(best, acc[j][k]);
             if (pj < HW) out_clu[(size_t)b * HW + pj] = best;
         }
     }

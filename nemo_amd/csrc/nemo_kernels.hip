@@ -69,6 +69,7 @@ struct nemo_mesh_s {
     float* memory_t;   // [C,V]
     void* bank_frag;   // vertex bank as f16-piece MFMA fragments (table_gemm.hip), or null when C does not qualify
     int32_t* faces_outward;   // [F,3]: the faces wound counter-clockwise seen from outside, or null (see orient_faces)
+    bool whole_outward;       // every face of faces_outward is wound outward (false when only some parts of the handle are closed solids)
     float aabb[6];            // xmin, ymin, zmin, xmax, ymax, zmax of the vertices
     int device;
     // several meshes back to back in one handle (a multi-class bank): part l = vertices [v0, v0 + nv), faces [f0, f0 + nf)
@@ -241,6 +242,7 @@ static int mesh_create_impl(nemo_mesh_s* m, const float* verts, const int32_t* f
     if (orient_faces(m->host_verts, m->host_faces, V, F, &oriented)) {
         HIP_TRY(hipMalloc((void**)&m->faces_outward, sizeof(int32_t) * 3 * F));
         HIP_TRY(hipMemcpy(m->faces_outward, oriented.data(), sizeof(int32_t) * 3 * F, hipMemcpyHostToDevice));
+        m->whole_outward = true;
     }
     return NEMO_OK;
 }
@@ -250,7 +252,7 @@ extern "C" int nemo_mesh_create(const float* verts, const int32_t* faces, int32_
     nemo_mesh_s* m = new (std::nothrow) nemo_mesh_s();
     if (!m) return fail(NEMO_ERR_INVALID, "out of host memory");
     m->V = V; m->F = F; m->C = 0; m->memory = nullptr; m->memory_t = nullptr; m->bank_frag = nullptr; m->faces_outward = nullptr;
-    m->verts = nullptr; m->faces = nullptr; m->d_parts = nullptr;
+    m->verts = nullptr; m->faces = nullptr; m->d_parts = nullptr; m->whole_outward = false;
     int rc = NEMO_ERR_INVALID;
     try { rc = mesh_create_impl(m, verts, faces, V, F); } catch (const std::bad_alloc&) { rc = fail(NEMO_ERR_INVALID, "out of host memory"); }
     if (rc) { (void)nemo_mesh_destroy(m); return rc; }       // frees whatever was allocated before the failure
@@ -260,21 +262,22 @@ extern "C" int nemo_mesh_create(const float* verts, const int32_t* faces, int32_
 
 // Several meshes in one handle: part l = the next vert_counts[l] vertices and the next face_counts[l] faces (host
 // arrays).  Every face of a part must index vertices of that part.
-extern "C" int nemo_mesh_set_parts(nemo_mesh_t m, const int32_t* vert_counts, const int32_t* face_counts, int32_t n_parts) {
-    if (!m || !vert_counts || !face_counts || n_parts <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: bad argument");
+static int mesh_set_parts_impl(nemo_mesh_t m, const int32_t* vert_counts, const int32_t* face_counts, int32_t n_parts) {
     std::vector<nemo::MeshPart> parts((size_t)n_parts);
-    int v0 = 0, f0 = 0, fmax = 1;
+    int v0 = 0, f0 = 0;
     for (int l = 0; l < n_parts; ++l) {
         if (vert_counts[l] <= 0 || face_counts[l] <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: part %d is empty", l);
         parts[l].v0 = v0; parts[l].nv = vert_counts[l]; parts[l].f0 = f0; parts[l].nf = face_counts[l];
         v0 += vert_counts[l]; f0 += face_counts[l];
         if (v0 > m->V || f0 > m->F) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: the parts exceed the mesh");
-        fmax = face_counts[l] > fmax ? face_counts[l] : fmax;
     }
     if (v0 != m->V || f0 != m->F)
         return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: the parts hold %d vertices / %d faces, the mesh %d / %d", v0, f0, m->V, m->F);
-    int fb = 9;
-    while ((1 << fb) <= fmax) ++fb;
+    // Every part is treated as the mesh it is in a handle of its own: its own depth-key format (face bits from its own
+    // face count) and its own closed-solid test (vertices are welded within the part only: two category meshes may share
+    // a corner position without sharing an edge).
+    std::vector<int32_t> outward(m->host_faces);
+    bool any_outward = false, all_outward = true;
     for (int l = 0; l < n_parts; ++l) {
         nemo::MeshPart& q = parts[l];
         for (int t = 3 * q.f0; t < 3 * (q.f0 + q.nf); ++t)
@@ -282,10 +285,28 @@ extern "C" int nemo_mesh_set_parts(nemo_mesh_t m, const int32_t* vert_counts, co
                 return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: face %d of part %d uses vertex %d of another part", t / 3 - q.f0, l,
                             m->host_faces[t]);
         box_of(m->host_verts, q.v0, q.nv, q.aabb);
+        int fb = 9;
+        while ((1 << fb) <= q.nf) ++fb;
         q.face_bits = fb;
         depth_range(q.aabb, fb, &q.depth_margin, &q.depth_scale, &q.depth_qmax);
+        std::vector<float> pv(m->host_verts.begin() + 3 * (size_t)q.v0, m->host_verts.begin() + 3 * (size_t)(q.v0 + q.nv));
+        std::vector<int32_t> pf((size_t)3 * q.nf), po;
+        for (int t = 0; t < 3 * q.nf; ++t) pf[t] = m->host_faces[3 * (size_t)q.f0 + t] - q.v0;
+        q.outward = orient_faces(pv, pf, q.nv, q.nf, &po) ? 1 : 0;
+        all_outward = all_outward && q.outward;
+        if (q.outward) {
+            any_outward = true;
+            for (int t = 0; t < 3 * q.nf; ++t) outward[3 * (size_t)q.f0 + t] = po[t] + q.v0;
+        }
     }
     HIP_TRY(hipSetDevice(m->device));
+    if (any_outward) {
+        if (!m->faces_outward) HIP_TRY(hipMalloc((void**)&m->faces_outward, sizeof(int32_t) * 3 * (size_t)m->F));
+        HIP_TRY(hipMemcpy(m->faces_outward, outward.data(), sizeof(int32_t) * 3 * (size_t)m->F, hipMemcpyHostToDevice));
+    } else if (m->faces_outward) {
+        (void)hipFree(m->faces_outward);
+        m->faces_outward = nullptr;
+    }
     nemo::MeshPart* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, sizeof(nemo::MeshPart) * n_parts));
     if (hipMemcpy(d, parts.data(), sizeof(nemo::MeshPart) * n_parts, hipMemcpyHostToDevice) != hipSuccess) {
@@ -295,7 +316,14 @@ extern "C" int nemo_mesh_set_parts(nemo_mesh_t m, const int32_t* vert_counts, co
     if (m->d_parts) (void)hipFree(m->d_parts);
     m->d_parts = d;
     m->parts = parts;
+    m->whole_outward = any_outward && all_outward;
     return NEMO_OK;
+}
+
+extern "C" int nemo_mesh_set_parts(nemo_mesh_t m, const int32_t* vert_counts, const int32_t* face_counts, int32_t n_parts) {
+    if (!m || !vert_counts || !face_counts || n_parts <= 0) return fail(NEMO_ERR_INVALID, "nemo_mesh_set_parts: bad argument");
+    try { return mesh_set_parts_impl(m, vert_counts, face_counts, n_parts); }
+    catch (const std::bad_alloc&) { return fail(NEMO_ERR_INVALID, "out of host memory"); }
 }
 
 extern "C" int nemo_mesh_set_memory(nemo_mesh_t m, const float* memory, int32_t C, void* stream) {
@@ -628,7 +656,7 @@ __global__ void clutter_kernel(const float* __restrict__ feat, const float* __re
         const float* ck = cl + k * C;
 #pragma unroll 8
         for (int c = 0; c < C; ++c) acc = __builtin_fmaf(f[(size_t)c * HW], ck[c], acc);
-        best = (k == 0) ? acc : fmaxf(best, acc);
+        best = (k == 0) ? acc : max_nan(best, acc);     // torch.max over the clutter vectors: a NaN score stays NaN
     }
     out[(size_t)b * HW + p] = best;
 }
@@ -820,10 +848,18 @@ constexpr int kMaxDevices = 64;
 static float* g_scratch_ptr[kMaxDevices] = {};
 static std::mutex g_scratch_mutex;
 
-static int static_scratch(float** out) {
-    int dev = -1;
-    HIP_TRY(hipGetDevice(&dev));
+// The array's address on the device that will run the call: the device that owns `stream` (the current device for the
+// null stream).  The first call on a device looks the address up (with that device current; the runtime may load the
+// code object then, which is why that first call must not come under graph capture); later calls only read the cache.
+static int static_scratch(hipStream_t stream, float** out) {
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    int dev = cur;
+    if (stream) HIP_TRY(hipStreamGetDevice(stream, &dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(NEMO_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    if (dev != cur)
+        return fail(NEMO_ERR_STATE, "nemo_grid_score_static: the stream belongs to device %d, the current device is %d (make the "
+                    "stream's device current: every GPU holds its own copy of the scratch array)", dev, cur);
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         void* p = nullptr;
@@ -846,7 +882,7 @@ extern "C" int nemo_grid_score_static(const float* pre, const float* feat, const
                     "nemo_grid_score_static: %d poses x %d images x %d pixels need %zu bytes of partial sums, the static scratch "
                     "array holds %zu (use nemo_grid_score with a workspace)", N, B, HW, need, (size_t)NEMO_STATIC_SCRATCH_BYTES);
     float* partial = nullptr;
-    const int rc = static_scratch(&partial);
+    const int rc = static_scratch((hipStream_t)stream, &partial);
     if (rc) return rc;
     // every partial sum the finalize kernel reads is written by the scoring kernel of this call: nothing to clear
     return nemo_grid_score(pre, feat, clu, N, B, C, HW, out_loss, out_argmin, out_min, partial, need, stream);
@@ -1109,7 +1145,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         if ((unsigned)part < (unsigned)a.n_parts) {
             const MeshPart q = a.parts[part];
             rc.verts = a.rc.verts + 3 * (size_t)q.v0; rc.faces = a.rc.faces + 3 * (size_t)q.f0; rc.vbase = q.v0;
-            rc.V = q.nv; rc.F = q.nf;
+            rc.V = q.nv; rc.F = q.nf; rc.outward = __builtin_amdgcn_readfirstlane(q.outward);
             // (uniform values, pinned to scalar registers: they live over the whole step loop)
             auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
 #pragma unroll
@@ -1556,7 +1592,7 @@ extern "C" int nemo_raster_forms(nemo_mesh_t m, const nemo_camera* cam, const fl
     if (m->F >= (1 << 16)) return fail(NEMO_ERR_UNSUPPORTED, "nemo_raster_forms: meshes below 65536 faces");
     RasterFormsArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
-    a.rc.outward = m->faces_outward != nullptr;
+    a.rc.outward = m->faces_outward != nullptr && m->whole_outward;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);
@@ -1602,7 +1638,7 @@ static int solve_impl(nemo_mesh_t m, const nemo_camera* cam, const float* feat, 
     if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve: negative step count");
     SolveArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
-    a.rc.outward = m->faces_outward != nullptr;
+    a.rc.outward = m->faces_outward != nullptr && m->whole_outward;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     // LDS plan: for the whole handle, or for its largest part when every hypothesis renders one part
@@ -1750,7 +1786,7 @@ extern "C" int nemo_solve_flow(nemo_mesh_t m, const nemo_camera* cam, const floa
     if (opt->steps < 0) return fail(NEMO_ERR_INVALID, "nemo_solve_flow: negative step count");
     SolveArgs a;
     a.rc.verts = m->verts; a.rc.faces = m->faces_outward ? m->faces_outward : m->faces; a.rc.V = m->V; a.rc.F = m->F;
-    a.rc.outward = m->faces_outward != nullptr;
+    a.rc.outward = m->faces_outward != nullptr && m->whole_outward;
     for (int k = 0; k < 6; ++k) a.rc.aabb[k] = m->aabb[k];
     a.rc.cc = make_cam_const(cam->H, cam->W, cam->focal);
     int rcode = plan_solve(cam->H, cam->W, m->V, m->F, kSolveThreads, m->aabb, &a.rc);

@@ -153,6 +153,7 @@ struct MeshPart {
     float aabb[6];
     float depth_margin, depth_scale, depth_qmax;
     int face_bits;
+    int outward;                // this part's faces in the handle's outward-wound copy are wound outward (closed solid)
 };
 
 struct RasterCtx {

@@ -230,7 +230,11 @@ def resolve_occ(seg_maps, score_maps):
     overlap is judged on the ORIGINAL masks: a proposal's claim is its score summed over the overlap plus half its
     score over the rest of its own mask, and the proposal with the smaller claim (the later one at equal claims)
     gives the overlap up.  -> (index map: 0 = nobody, k + 1 = proposal k, the first one where several still claim a
-    pixel; the reduced masks)."""
+    pixel; the reduced masks).
+    Deliberate deviation: the reference's last lines add every reduced mask into mask 0 IN PLACE (`sm = seg_maps_copy[0];
+    sm += seg_maps_copy[i]`) before the arg-max, so what it returns is mask 0 = the sum of all kept masks and an index
+    map that says 1 wherever any proposal keeps a pixel.  That aliasing is taken for a bug (the output is only drawn
+    for debugging) and is not reproduced: mask 0 stays proposal 0's and the index map names the proposals."""
     masks = np.asarray(seg_maps)
     scores = np.asarray(score_maps)
     on = masks == 1

@@ -1,6 +1,6 @@
 """Generates the committed fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY.
 
-    python oracle/gen_golden.py [leaf] [small] [full] [grid]
+    python oracle/gen_golden.py [leaf] [small] [full] [grid] [solves]
 
 leaf   tests/golden/leaf_golden.npz   - outputs of the reference's OWN dependency-free leaf files
        (nemo/utils/general.py, pose.py, features.py, flow_warp.py), loaded standalone from
@@ -13,6 +13,9 @@ full   tests/golden/oracle_full.npz   - oracle outputs at BASELINE size (80x100x
 grid   tests/golden/oracle_full_grid.npz - BASELINE-size pose-grid scoring: losses and arg-min of 4 images against
        the 144-pose grid, the 300-step refinement of the 8 best grid poses of 2 of them (global batch 2), and a
        6-D slice: 2 off-centre images x the 576-pose grid (4 distances) x 3 principal-point samples.
+solves tests/golden/oracle_full_solves.npz - BASELINE-size solves beyond one mesh / 3-D: render-and-compare
+       classification of 2 images against 12 category cuboids (144-pose grid + 300 steps per pair, final losses, classes)
+       and a 6-D solve of 2 off-centre images (576 poses x 3 principal samples, then 300 steps over 6 parameters).
 
 The render-path fixtures come from the oracle itself (parity with PyTorch3D is unpinned: no PyTorch3D
 here); they freeze the oracle so that a change in its behaviour, or a difference between machines, is
@@ -30,7 +33,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import refsolver as R          # noqa: E402
-from tests.common import GRID_CFG, Scene, random_poses   # noqa: E402
+from tests.common import GRID_CFG, Scene, categories, full_size_vertex_counts, random_poses   # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 REF = "/root/reference"
@@ -167,9 +170,54 @@ def gen_full_grid():
     print("oracle_full_grid.npz written")
 
 
+def gen_full_solves():
+    """BASELINE configs[4] and [3] at full size: what MultiCategorySolver.classify and solve_pose(dof=6) are checked against."""
+    out = {}
+    # --- classification: nemo_cls.py:262-282 - every image solved against every category mesh, smallest final loss wins
+    n_cat, labels, first_seed = 12, (3, 8), 700
+    meshes, counts, mem, clutter = categories(n_cat, 128, number_vertices=full_size_vertex_counts, n_clutter=2560)
+    cam = R.Camera(80, 100, 375.0)
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    refs = [R.MeshInterpolateModuleRef(v, f, mem[o:o + c], cam) for (v, f), o, c in zip(meshes, offs, counts)]
+    fm = torch.stack([R.synthetic_feature_map(refs[lab], clutter, first_seed + i)[0] for i, lab in enumerate(labels)])
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    scores, poses, init_idx = np.zeros((2, n_cat), np.float32), np.zeros((2, n_cat, 4), np.float32), np.zeros((2, n_cat), np.int64)
+    for c in range(n_cat):
+        maps, cs, ths = R.get_pre_render_samples(refs[c], az, el, th, di)
+        preds, info = R.solve_pose(refs[c], fm, clutter, cs, ths, maps, epochs=300)
+        for i in range(2):
+            f = preds[i]["final"][0]
+            scores[i, c] = f["score"]
+            poses[i, c] = (f["azimuth"], f["elevation"], f["theta"], f["distance"])
+        init_idx[:, c] = info["init_idx"].numpy()
+        print("category", c, scores[:, c], flush=True)
+    out.update(cls_labels=np.array(labels), cls_first_seed=np.int64(first_seed), cls_scores=scores, cls_poses=poses,
+               cls_init_idx=init_idx, cls_argmin=scores.argmin(axis=1))
+    # --- 6-D: batch_solve_pose.py:264-338 with dof 6 (the images and candidates of the grid fixture's 6-D slice)
+    sc = Scene(80, 100, 128, 1000, 375.0, n_clutter=2560)
+    az6, el6, th6, di6, _, _ = R.get_param_samples(CFG6D)
+    maps6, cs6, ths6 = R.get_pre_render_samples(sc.ref, az6, el6, th6, di6)
+    cand = torch.tensor([[37.5, 30.0], [50.0, 40.0], [62.5, 50.0]])
+    gt_pr = torch.tensor([[39.0, 31.0], [60.0, 49.0]])
+    fms = []
+    for i in range(2):
+        sc.ref.principal = gt_pr[i:i + 1]
+        fms.append(R.synthetic_feature_map(sc.ref, sc.clutter, 260 + i)[0])
+    sc.ref.principal = None
+    preds, info = R.solve_pose(sc.ref, torch.stack(fms), sc.clutter, cs6, ths6, maps6, principal=cand, dof=6, epochs=300)
+    fin = np.array([[p["final"][0][k] for k in ("azimuth", "elevation", "theta", "distance")] + p["final"][0]["principal"]
+                    + [p["final"][0]["score"]] for p in preds], dtype=np.float32)
+    out.update(six_solve_first_seed=np.int64(260), six_solve_gt_principal=gt_pr.numpy(), six_solve_candidates=cand.numpy(),
+               six_solve_final=fin, six_solve_use=info["init_idx"].numpy(), six_solve_init_C=info["init_C"].numpy(),
+               six_solve_init_theta=info["init_theta"].numpy())
+    print("6-D solve", fin, flush=True)
+    np.savez_compressed(os.path.join(GOLD, "oracle_full_solves.npz"), **out)
+    print("oracle_full_solves.npz written")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["leaf", "small", "full", "grid"]
+    what = sys.argv[1:] or ["leaf", "small", "full", "grid", "solves"]
     torch.set_num_threads(8)
     if "leaf" in what:
         gen_leaf()
@@ -179,3 +227,5 @@ if __name__ == "__main__":
         gen_full()
     if "grid" in what:
         gen_full_grid()
+    if "solves" in what:
+        gen_full_solves()

@@ -474,6 +474,30 @@ def get_init_pos_rendered_dim0(samples_maps, samples_pos, samples_theta, predict
     return samples_pos[idx], samples_theta[idx], torch.min(loss, dim=0)[0], idx
 
 
+@torch.no_grad()
+def get_init_pos(inter_module, samples_pos, samples_theta, predicted_maps, clutter_scores=None, reset_distance=None):
+    """batch_solve_pose.py:168-191 (pre_render: false): every grid pose is rendered when it is scored - once for the whole
+    batch, or, with reset_distance [b], per image at that image's own distance along the pose's viewing direction.
+    Without clutter scores the loss is loss_fg_only (:27-28).  -> (campos [b,3], theta [b], min loss [b], index [b])."""
+    b = predicted_maps.shape[0]
+    red = lambda x: torch.mean(x, dim=(1, 2))
+    out = []
+    for pos_, theta_ in zip(samples_pos, samples_theta):
+        if reset_distance is not None:
+            C = torch.nn.functional.normalize(pos_[None]) * reset_distance[:, None]
+            maps_ = inter_module(C, theta_[None].expand(b))
+        else:
+            maps_ = inter_module(pos_[None], theta_[None]).expand(b, -1, -1, -1)
+        obj = torch.einsum('nchw,nchw->nhw', maps_, predicted_maps)
+        if clutter_scores is None:
+            out.append(torch.ones(1) - red(obj))
+        else:
+            out.append(torch.ones(1) - (red(torch.max(obj, clutter_scores)) - red(clutter_scores)))
+    loss = torch.stack(out)                       # [n, b]
+    mn, idx = torch.min(loss, dim=0)
+    return samples_pos[idx], samples_theta[idx], mn, idx
+
+
 def align_no_centered(maps_source, distance_source, principal_source, maps_target_shape, distance_target,
                       principal_target, padding_mode='zeros'):
     """batch_solve_pose.py:65-90."""

@@ -53,3 +53,26 @@ def random_poses(n, seed=0, dist=(4.0, 6.0)):
 def angle_diff_deg(a, b):
     d = (a - b + math.pi) % (2 * math.pi) - math.pi
     return abs(d) * 180.0 / math.pi
+
+
+def categories(n, C, seed=0, number_vertices=lambda i: 110 + 9 * i, n_clutter=64):
+    """n cuboids of different extents and vertex counts + one bank holding their vertex features back to back.
+    -> (meshes [(verts, faces)], vertex counts, bank rows [sum V_i, C], clutter [1, C])."""
+    rng = np.random.RandomState(seed)
+    meshes = []
+    for i in range(n):
+        ex = 0.14 + 0.12 * rng.rand(3)                      # half extents
+        ex[1] += 0.15                                       # longer along y, like a vehicle
+        v, f = R.cuboid_mesh((-ex[0], ex[0]), (-ex[1], ex[1]), (-ex[2], ex[2]), number_vertices=number_vertices(i))
+        meshes.append((v, f))
+    g = torch.Generator().manual_seed(seed + 5)
+    counts = [m[0].shape[0] for m in meshes]
+    mem = torch.nn.functional.normalize(torch.randn(sum(counts), C, generator=g), dim=1)
+    rows = torch.nn.functional.normalize(torch.randn(n_clutter, C, generator=g), dim=1)
+    clutter = R.normalize_features(torch.mean(rows, dim=0)).unsqueeze(0)
+    return meshes, counts, mem, clutter
+
+
+def full_size_vertex_counts(i):
+    """Requested vertex counts of the 12 full-size category cuboids: their face counts straddle 1024 and 2048."""
+    return 560 + 70 * i

@@ -1,0 +1,188 @@
+"""The BASELINE configs beyond one mesh / 3-D at their full size (80 x 100 x 128), against oracle fixtures
+(tests/golden/oracle_full_solves.npz, written by oracle/gen_golden.py solves), and the branches of the drop-in solver
+that only large calls or `pre_render: false` take."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refsolver as R
+from tests.common import GRID_CFG, Scene, angle_diff_deg, categories, full_size_vertex_counts
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CFG6D = dict(GRID_CFG, dist_sample=dict(min=3.0, max=9.0, num=4))
+
+
+def _rasterizer(H, W, focal):
+    import nemo_amd
+    cams = nemo_amd.PerspectiveCameras(focal_length=focal, principal_point=((W // 2, H // 2),), image_size=((H, W),), in_ndc=False)
+    rs = nemo_amd.RasterizationSettings(image_size=(H, W), blur_radius=0.0, faces_per_pixel=1, bin_size=0)
+    return nemo_amd.MeshRasterizer(cameras=cams, raster_settings=rs)
+
+
+def test_classification_twelve_categories_full_size(gpu):
+    """configs[4] at BASELINE size: 2 images against 12 category cuboids (face counts 980 .. 2548, so the parts of the
+    one mesh handle use three different depth-key formats), 144-pose grid + 300 steps per (image, category) pair, all
+    24 pairs in one solve launch.  Final losses against the oracle's category-by-category solves
+    (nemo_cls.py:262-282): the class (arg-min) is equal; the winning pair, which converges, is held to the solver's bars
+    (0.5 degrees, 2e-3); a pair of an image with a wrong category ends wherever 300 Adam steps on a loss surface without
+    a basin take it, so those are held to losing by the oracle's margin."""
+    import nemo_amd
+    from nemo_amd.utils import default_pose3d_config
+    gold = np.load(os.path.join(GOLD, "oracle_full_solves.npz"))
+    n_cat = 12
+    meshes, counts, mem, clutter = categories(n_cat, 128, number_vertices=full_size_vertex_counts, n_clutter=2560)
+    assert sorted({int(f.shape[0]).bit_length() for _, f in meshes}) == [10, 11, 12]
+    bank = nemo_amd.FeatureBankNeMo(input_size=128, num_pos=sum(counts), num_noise=0, mesh_n_list=counts)
+    bank.load_memory(mem)
+    cfg = default_pose3d_config()
+    solver = nemo_amd.MultiCategorySolver(cfg, [f"cat{i}" for i in range(n_cat)], meshes, bank, clutter, _rasterizer(80, 100, 375.0),
+                                          device=str(gpu), dof=3)
+    cam = R.Camera(80, 100, 375.0)
+    offs = bank.mesh_offsets()
+    labels = [int(x) for x in gold["cls_labels"]]
+    fms = []
+    for i, lab in enumerate(labels):
+        ref = R.MeshInterpolateModuleRef(meshes[lab][0], meshes[lab][1], mem[offs[lab]:offs[lab] + counts[lab]], cam)
+        fms.append(R.synthetic_feature_map(ref, clutter, int(gold["cls_first_seed"]) + i)[0])
+    fm = torch.stack(fms)
+    names, scores, preds = solver.classify(fm.to(gpu))
+    ref_scores, ref_poses = gold["cls_scores"], gold["cls_poses"]
+    assert list(scores.argmin(axis=1)) == list(gold["cls_argmin"]) == labels
+    assert names == [f"cat{lab}" for lab in labels]
+    for i, lab in enumerate(labels):
+        got = preds[i][lab]["final"][0]
+        assert abs(got["score"] - float(ref_scores[i, lab])) < 2e-3, (i, got, ref_scores[i, lab])
+        for k, name in enumerate(("azimuth", "elevation", "theta")):
+            assert angle_diff_deg(got[name], float(ref_poses[i, lab, k])) < 0.5, (i, name, got, ref_poses[i, lab])
+        assert abs(got["distance"] - float(ref_poses[i, lab, 3])) < 0.15
+        # every wrong category loses by about the oracle's margin (0.1 and more here), here as there
+        margin = np.delete(ref_scores[i], lab).min() - ref_scores[i, lab]
+        assert np.delete(scores[i], lab).min() - scores[i, lab] > 0.9 * margin
+    # the wrong pairs, for the record: most of them agree to the score bar as well
+    close = np.abs(scores - ref_scores) < 2e-3
+    assert close.mean() > 0.5, (scores, ref_scores)
+    # the one-launch solver against the per-category path on a category of each depth-key format: bit for bit
+    for c in (0, labels[0], 11):
+        maps, cs, ths = solver.grids[c]
+        pc = nemo_amd.solve_pose(cfg, fm.to(gpu), solver.modules[c], clutter.to(gpu), cs, ths, maps, device=gpu)
+        for i in range(2):
+            assert pc[i]["final"][0] == preds[i][c]["final"][0], (c, i)
+
+
+def test_six_dof_solve_full_size(gpu):
+    """configs[3]'s solve at BASELINE size: 2 off-centre images, 576 poses x 3 principal samples, then 300 Adam steps over
+    camera position, theta and the principal point (batch_solve_pose.py:264-338), against the oracle's."""
+    import nemo_amd
+    from nemo_amd.utils import ConfigNode, default_pose3d_config
+    gold = np.load(os.path.join(GOLD, "oracle_full_solves.npz"))
+    sc = Scene(80, 100, 128, 1000, 375.0, device=gpu, n_clutter=2560)
+    cfg = default_pose3d_config()
+    for k, v in CFG6D.items():
+        setattr(cfg.inference, k, ConfigNode(v))
+    az, el, th, di, _, _ = R.get_param_samples(CFG6D)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    assert cs.shape[0] == 576
+    gt_pr = torch.from_numpy(gold["six_solve_gt_principal"])
+    fms = []
+    for i in range(2):
+        sc.ref.principal = gt_pr[i:i + 1]
+        fms.append(R.synthetic_feature_map(sc.ref, sc.clutter, int(gold["six_solve_first_seed"]) + i)[0])
+    sc.ref.principal = None
+    cand = torch.from_numpy(gold["six_solve_candidates"])
+    preds = nemo_amd.solve_pose(cfg, torch.stack(fms).to(gpu), sc.mod, sc.clutter.to(gpu), cs, ths, maps, device=gpu,
+                                principal=cand.to(gpu), dof=6)
+    fin = gold["six_solve_final"]            # azimuth, elevation, theta, distance, px, py, score
+    for i in range(2):
+        got = preds[i]["final"][0]
+        for k, name in enumerate(("azimuth", "elevation", "theta")):
+            assert angle_diff_deg(got[name], float(fin[i, k])) < 0.5, (i, name, got, fin[i])
+        assert abs(got["distance"] - float(fin[i, 3])) < 0.15, (got, fin[i])
+        assert abs(got["principal"][0] - float(fin[i, 4])) < 0.2 and abs(got["principal"][1] - float(fin[i, 5])) < 0.2, (got, fin[i])
+        assert abs(got["score"] - float(fin[i, 6])) < 2e-3
+        # and the answer is where the image was rendered: principal point within a pixel of the truth
+        assert abs(got["principal"][0] - float(gt_pr[i, 0])) < 1.0 and abs(got["principal"][1] - float(gt_pr[i, 1])) < 1.0
+
+
+@pytest.mark.parametrize("with_clutter", [True, False])
+def test_get_init_pos_without_pre_render(gpu, with_clutter):
+    """`pre_render: false` (batch_solve_pose.py:168-191): the pose grid rendered on the fly - once for the batch, and per
+    image at its own distance (reset_distance) - against the oracle's pose-by-pose loop; and solve_pose(pre_render=False)
+    end to end."""
+    import nemo_amd
+    from nemo_amd import batch_solve_pose as bsp
+    from nemo_amd import ops
+    from nemo_amd.utils import default_pose3d_config
+    sc = Scene(40, 50, 32, 150, 375.0 / 2, device=gpu)
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    poses = [(a, e, t, d) for a in az for e in el for t in th for d in di]
+    cs_ref = torch.cat([R.camera_position_from_spherical_angles(d, e, a) for a, e, t, d in poses])
+    th_ref = torch.tensor([t for _, _, t, _ in poses], dtype=torch.float32)
+    B = 3
+    fm, _ = sc.feature_maps(B, first_seed=70)
+    clu_ref = R.clutter_score(fm, sc.clutter) if with_clutter else None
+    fmd = fm.to(gpu)
+    clu = ops.clutter_score(fmd, sc.clutter.to(gpu)) if with_clutter else None
+    cs, ths = cs_ref.to(gpu), th_ref.to(gpu)
+    # one rendering of the grid for the whole batch
+    C_r, t_r, mn_r, idx_r = R.get_init_pos(sc.ref, cs_ref, th_ref, fm, clu_ref)
+    C_g, t_g, mn_g = bsp.get_init_pos(sc.mod, cs, ths, fmd, clu)
+    assert torch.equal(C_g.cpu(), C_r) and torch.equal(t_g.cpu(), t_r)
+    assert float(((mn_g.cpu() - mn_r).abs() / mn_r.abs()).max()) < 1e-4
+    # every image at its own distance
+    dist = torch.tensor([4.0, 5.5, 7.0])
+    C_r, t_r, mn_r, idx_r = R.get_init_pos(sc.ref, cs_ref, th_ref, fm, clu_ref, reset_distance=dist)
+    C_g, t_g, mn_g = bsp.get_init_pos(sc.mod, cs, ths, fmd, clu, reset_distance=dist.to(gpu))
+    assert torch.equal(C_g.cpu(), C_r) and torch.equal(t_g.cpu(), t_r)
+    assert float(((mn_g.cpu() - mn_r).abs() / mn_r.abs()).max()) < 1e-4
+    if not with_clutter:
+        return
+    # the drop-in entry point with pre_render=False: the same answer as with the pre-rendered grid (same arg-min, same solve)
+    cfg = default_pose3d_config()
+    maps, cs2, ths2 = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    a = nemo_amd.solve_pose(cfg, fmd, sc.mod, sc.clutter.to(gpu), cs2, ths2, maps, device=gpu)
+    b = nemo_amd.solve_pose(cfg, fmd, sc.mod, sc.clutter.to(gpu), cs2, ths2, None, device=gpu, pre_render=False)
+    for i in range(B):
+        assert a[i]["final"][0] == b[i]["final"][0]
+
+
+def test_solve_pose_large_call_takes_the_on_demand_branch(gpu, monkeypatch):
+    """From 256 hypotheses per call on, solve_pose lets the solve compute its similarity-table tiles itself
+    (nemo_solve_features) instead of building the complete table first.  A 256-image call must give every image what a
+    smaller call (complete table) gives it under the same loss normaliser, bit for bit."""
+    import nemo_amd
+    from nemo_amd import batch_solve_pose as bsp
+    from nemo_amd import ops
+    from nemo_amd.utils import default_pose3d_config
+    sc = Scene(40, 50, 32, 150, 375.0 / 2, device=gpu)
+    az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    B = 256
+    g = torch.Generator().manual_seed(15)
+    u = torch.rand(B, 3, generator=g)
+    gaz, gel, gth = u[:, 0] * 2 * math.pi, -math.pi / 6 + u[:, 1] * math.pi / 2, -math.pi / 6 + u[:, 2] * math.pi / 3
+    campos = R.camera_position_from_spherical_angles(torch.full((B,), 5.0), gel, gaz).to(gpu)
+    with torch.no_grad():
+        fm = sc.mod(campos, gth.float().to(gpu))
+    clutter = sc.clutter.to(gpu)
+    bg = (fm.abs().sum(dim=1, keepdim=True) == 0).float()
+    noise = torch.randn(fm.shape, generator=torch.Generator().manual_seed(16)).to(gpu)
+    fm = torch.nn.functional.normalize(fm + bg * clutter.view(1, -1, 1, 1) + 0.5 / math.sqrt(sc.C) * noise, dim=1).contiguous()
+    cfg = default_pose3d_config()
+    taken = []
+    real = ops.solve_from_features
+    monkeypatch.setattr(ops, "solve_from_features", lambda *a, **k: (taken.append(1), real(*a, **k))[1])
+    big = nemo_amd.solve_pose(cfg, fm, sc.mod, clutter, cs, ths, maps, device=gpu)
+    assert taken == [1] and len(big) == B
+    part = nemo_amd.solve_pose(cfg, fm[40:140].contiguous(), sc.mod, clutter, cs, ths, maps, device=gpu, global_batch=B)
+    assert taken == [1]                                     # the smaller call built the complete table
+    for i in range(100):
+        assert part[i]["final"][0] == big[40 + i]["final"][0], i
+    errs = sorted(R.pose_error(dict(azimuth=float(gaz[i]), elevation=float(gel[i]), theta=float(gth[i])), big[i]["final"][0])
+                  * 180 / math.pi for i in range(B))
+    assert errs[B // 2] < 1.0, errs[B // 2]
+    assert bsp.ON_DEMAND_MIN_IMAGES == 256

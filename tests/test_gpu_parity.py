@@ -695,17 +695,22 @@ def test_golden_solve(which, name, B, request):
     assert rel_err(clu, torch.from_numpy(gold["solve_clutter_map"])) < REL
     tab = ops.similarity_table(sc.mod.mesh, fm.to(sc.device))
     C0, th0 = torch.from_numpy(gold["solve_C0"]).to(sc.device), torch.from_numpy(gold["solve_th0"]).to(sc.device)
-    pose, lh = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu, C0, th0, steps=300, history=True)
-    pose, lh = pose.cpu(), lh.cpu()
     ref_hist = torch.from_numpy(gold["solve_loss_hist"])
-    assert rel_err(lh[:, :4], ref_hist[:, :4]) < REL
     _, e_r, a_r = R.camera_position_to_spherical_angle(torch.from_numpy(gold["solve_C"]))
-    _, e_g, a_g = R.camera_position_to_spherical_angle(pose[:, 0:3])
-    for i in range(B):
-        assert angle_diff_deg(float(a_g[i]), float(a_r[i])) < 0.5
-        assert angle_diff_deg(float(e_g[i]), float(e_r[i])) < 0.5
-        assert angle_diff_deg(float(pose[i, 3]), float(gold["solve_theta"][i])) < 0.5
-    assert float((pose[:, 6] - torch.from_numpy(gold["solve_scores"])).abs().max()) < 2e-3
+    # both forms of the solve against the frozen trajectory: on a complete similarity table, and computing its own
+    # table tiles from the feature maps (the form the bench times)
+    on_table = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu, C0, th0, steps=300, history=True)
+    on_demand = ops.solve_from_features(sc.mod.mesh, sc.mod.camera(), fm.to(sc.device), clu, C0, th0, steps=300, history=True)
+    for pose, lh in (on_table, on_demand):
+        pose, lh = pose.cpu(), lh.cpu()
+        assert rel_err(lh[:, :4], ref_hist[:, :4]) < REL
+        _, e_g, a_g = R.camera_position_to_spherical_angle(pose[:, 0:3])
+        for i in range(B):
+            assert angle_diff_deg(float(a_g[i]), float(a_r[i])) < 0.5
+            assert angle_diff_deg(float(e_g[i]), float(e_r[i])) < 0.5
+            assert angle_diff_deg(float(pose[i, 3]), float(gold["solve_theta"][i])) < 0.5
+        assert float((pose[:, 6] - torch.from_numpy(gold["solve_scores"])).abs().max()) < 2e-3
+    assert torch.equal(on_table[0], on_demand[0]) and torch.equal(on_table[1], on_demand[1])
     # one-step gradient check through the optimiser: after one Adam step every parameter has moved by
     # lr in the direction opposite to the oracle's gradient sign
     one, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), tab, clu, C0, th0, steps=1)
@@ -1444,6 +1449,16 @@ def test_nan_features_stay_nan_on_the_matrix_cores(small):
     loss_c, _, _ = ops.grid_score(None, fmd, clu, packed=maps._nemo_packed_grid)
     loss_cv, _, _ = ops.grid_score(maps.squeeze(1), fmd, clu)
     assert torch.isfinite(loss_c[0]).all() and torch.isnan(loss_c[1]).all() and torch.isnan(loss_cv[1]).all()
+    # torch.max over several clutter vectors (batch_solve_pose.py:214-225): a NaN in ONE vector makes its scores NaN, and
+    # the maximum with the other vector's finite scores stays NaN - in the clutter kernel and in the pass that scores the
+    # clutter vectors while it builds the grid scoring's operand fragments
+    two = torch.cat([sc.clutter, sc.clutter.flip(1)]).clone()
+    two[1, 5] = float("nan")
+    fm_ok = fm.clone()
+    fm_ok[1, 3, sc.H // 2, sc.W // 2] = 0.0
+    clu2 = ops.clutter_score(fm_ok.to(sc.device), two.to(sc.device))
+    clu2f, _, _, _ = ops.clutter_and_grid_score(fm_ok.to(sc.device), two.to(sc.device), maps._nemo_packed_grid)
+    assert torch.isnan(clu2).all() and torch.isnan(clu2f).all()
     # and in the optimisation loop: the reference's loss, gradients and therefore poses are NaN for that image
     C0, th0 = random_poses(2, seed=2, dist=(5.0, 5.0))
     pose, _ = ops.solve(sc.mod.mesh, sc.mod.camera(), table, clu, C0.to(sc.device), th0.to(sc.device), steps=3)

@@ -353,7 +353,9 @@ def test_top_k_grid_poses_are_best_first_and_stable(monkeypatch):
 
 def test_resolve_occ_known_answers():
     """Two overlapping masks: the one whose (overlap + half the rest) score is larger keeps the overlap; equal
-    claims go to the earlier proposal; disjoint masks are untouched."""
+    claims go to the earlier proposal; disjoint masks are untouched.  These are the intended semantics, not the
+    reference's output: solve_pose.py:350-402 ends by summing the kept masks into mask 0 in place (see resolve_occ's
+    docstring), which this implementation deliberately does not reproduce."""
     from nemo_amd.solve_pose_keypoint import resolve_occ
     seg = np.zeros((3, 4, 6), dtype=np.uint8)
     seg[0, :, 0:3] = 1

@@ -7,34 +7,17 @@ import pytest
 import torch
 
 from oracle import refsolver as R
-from tests.common import GRID_CFG, angle_diff_deg
+from tests.common import GRID_CFG, angle_diff_deg, categories
 
 pytestmark = pytest.mark.gpu
 
 H, W, C, FOCAL = 40, 50, 32, 375.0 / 2
 
 
-def _categories(n, seed=0):
-    """n cuboids of different extents and vertex counts + one bank holding their vertex features back to back."""
-    rng = np.random.RandomState(seed)
-    meshes = []
-    for i in range(n):
-        ex = 0.14 + 0.12 * rng.rand(3)                      # half extents
-        ex[1] += 0.15                                       # longer along y, like a vehicle
-        v, f = R.cuboid_mesh((-ex[0], ex[0]), (-ex[1], ex[1]), (-ex[2], ex[2]), number_vertices=110 + 9 * i)
-        meshes.append((v, f))
-    g = torch.Generator().manual_seed(seed + 5)
-    counts = [m[0].shape[0] for m in meshes]
-    mem = torch.nn.functional.normalize(torch.randn(sum(counts), C, generator=g), dim=1)
-    rows = torch.nn.functional.normalize(torch.randn(64, C, generator=g), dim=1)
-    clutter = R.normalize_features(torch.mean(rows, dim=0)).unsqueeze(0)
-    return meshes, counts, mem, clutter
-
-
-def _build(gpu, n_cat, dof, principal_samples=None, grid=GRID_CFG, epochs=300):
+def _build(gpu, n_cat, dof, principal_samples=None, grid=GRID_CFG, epochs=300, **cat_kw):
     import nemo_amd
     from nemo_amd.utils import ConfigNode, default_pose3d_config
-    meshes, counts, mem, clutter = _categories(n_cat)
+    meshes, counts, mem, clutter = categories(n_cat, C, **cat_kw)
     bank = nemo_amd.FeatureBankNeMo(input_size=C, num_pos=sum(counts), num_noise=0, mesh_n_list=counts)
     bank.load_memory(mem)
     assert bank.mesh_offsets() == [int(x) for x in np.concatenate([[0], np.cumsum(counts)[:-1]])]
@@ -108,7 +91,10 @@ def test_render_compare_classification(gpu):
     Scores equal the per-category path bit for bit and the oracle's within the solver's score bar; same classes."""
     import nemo_amd
     n_cat, B, epochs = 3, 3, 150
-    solver, cfg, refs, clutter = _build(gpu, n_cat, 3, epochs=epochs)
+    # the middle category has more than 512 faces, the others fewer: the parts of the one handle differ in the number of
+    # key bits that hold the face index, as each category's own handle does
+    solver, cfg, refs, clutter = _build(gpu, n_cat, 3, epochs=epochs, number_vertices=lambda i: (110, 400, 128)[i])
+    assert [int(m.faces.shape[0]) > 512 for m in solver.modules] == [False, True, False]
     fms, gts = zip(*[_image(refs[i % n_cat], clutter, 500 + i) for i in range(B)])
     fm = torch.stack(fms)
     names, scores, preds = solver.classify(fm.to(gpu))
