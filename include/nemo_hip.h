@@ -241,6 +241,17 @@ int nemo_similarity_table(nemo_mesh_t mesh, const float* feat, int32_t B, int32_
 int nemo_vertex_similarity(nemo_mesh_t mesh, const float* table, const float* clu, const int32_t* boxes_dev,
                            int32_t B, int32_t H, int32_t W, float* out, void* stream);
 
+/* The same similarity straight from the feature maps (no table is written or read): the vertex x pixel products of
+ * nemo_similarity_table are formed tile by tile on the matrix cores and reduced to the per-pixel maximum over the
+ * vertices inside the kernel; only one partial sum per (image, 128-pixel tile) reaches memory.  Same values as
+ * nemo_similarity_table + nemo_vertex_similarity up to the order of the final sum over pixels.  feat [B,C,HW],
+ * clu [B,HW] (nemo_clutter_score), boxes_dev [B,4] i32 device (r0,r1,c0,c1) or NULL; workspace: device scratch of
+ * nemo_vertex_similarity_workspace(B, HW) bytes.  C must be 16, 32, 64 or 128 (NEMO_ERR_UNSUPPORTED otherwise). */
+size_t nemo_vertex_similarity_workspace(int32_t B, int32_t HW);
+int nemo_vertex_similarity_features(nemo_mesh_t mesh, const float* feat, const float* clu, const int32_t* boxes_dev,
+                                    int32_t B, int32_t H, int32_t W, float* out, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+
 /* ---- pose optimisation -----------------------------------------------------------------------
  * The Adam loop of batch_solve_pose.solve_pose (batch_solve_pose.py:306-338), all `steps`
  * iterations inside one launch, one workgroup per hypothesis:

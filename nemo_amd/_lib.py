@@ -19,6 +19,7 @@ SYMBOLS = [
     "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_score_static", "nemo_grid_pack_bytes", "nemo_grid_pack",
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_clutter_grid_score_packed", "nemo_grid_fragments_bytes", "nemo_grid_score_fragments_workspace", "nemo_grid_score_fragments", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
+    "nemo_vertex_similarity_workspace", "nemo_vertex_similarity_features",
     "nemo_solve", "nemo_keypoint_corr", "nemo_solve_flow", "nemo_spherical_angles",
     "nemo_solve_features_workspace", "nemo_solve_features_supported", "nemo_solve_features", "nemo_render_nearest", "nemo_raster_forms",
     "nemo_project_keypoints", "nemo_gather_features", "nemo_gather_features_backward", "nemo_gather_idx", "nemo_mask_weight",
@@ -82,6 +83,9 @@ def load():
     lib.nemo_similarity_table_elems.restype = C.c_size_t
     lib.nemo_similarity_table.argtypes = [vp, f32p, i32, i32, f32p, vp]
     lib.nemo_vertex_similarity.argtypes = [vp, f32p, f32p, vp, i32, i32, i32, f32p, vp]
+    lib.nemo_vertex_similarity_workspace.argtypes = [i32, i32]
+    lib.nemo_vertex_similarity_workspace.restype = C.c_size_t
+    lib.nemo_vertex_similarity_features.argtypes = [vp, f32p, f32p, vp, i32, i32, i32, f32p, vp, C.c_size_t, vp]
     lib.nemo_solve.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, vp, f32p, f32p, f32p, vp, i32, i32, i32, i32,
                                C.POINTER(NemoAdam), f32p, f32p, vp]
     lib.nemo_mesh_set_parts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), i32]
@@ -108,7 +112,7 @@ def load():
         fn = getattr(lib, name)
         if name not in ("nemo_last_error", "nemo_version", "nemo_grid_score_workspace", "nemo_similarity_table_elems",
                         "nemo_grid_pack_bytes", "nemo_grid_score_packed_workspace", "nemo_grid_score_recentred_workspace", "nemo_grid_fragments_bytes",
-                        "nemo_grid_score_fragments_workspace",
+                        "nemo_grid_score_fragments_workspace", "nemo_vertex_similarity_workspace",
                         "nemo_solve_features_workspace"):
             fn.restype = C.c_int
     _lib = lib

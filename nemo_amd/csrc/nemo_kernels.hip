@@ -185,6 +185,8 @@ int launch_grid_mfma_recentred(const void* packed, const float* feat_src, const 
                                int h0, int w0, int border, const float* dist_src, const float* dist_tgt, const float* p_src,
                                const float* p_tgt, void* featp, float* partial, hipStream_t st);
 int launch_split_table(const void* frag, const float* feat, float* table, int V, int C, int HW, int B, hipStream_t st);
+int launch_vertex_max(const void* frag, const float* feat, const float* clu, const int32_t* boxes, int V, int C, int H, int Wd, int B,
+                      float* partial, float* out, hipStream_t st);
 int split_bank_blocks(int V);
 }
 
@@ -1063,7 +1065,7 @@ __global__ void vertex_similarity_kernel(const float* __restrict__ table, const 
         int p = (r0 + q / bw) * W + c0 + q % bw;
         const float* t = table + (size_t)b * table_image_elems(V, HW);
         float best = -__builtin_inff();
-        for (int v = 0; v < V; ++v) best = fmaxf(best, t[table_offset((V + 3) >> 2, v, p)]);
+        for (int v = 0; v < V; ++v) best = max_nan(best, t[table_offset((V + 3) >> 2, v, p)]);
         s += max_nan(best, clu[(size_t)b * HW + p]);
     }
     s = wave_sum(s);
@@ -1077,6 +1079,31 @@ extern "C" int nemo_vertex_similarity(nemo_mesh_t m, const float* table, const f
     if (B == 0) return NEMO_OK;
     if (!m || !table || !clu || !out || B < 0 || H <= 0 || W <= 0) return fail(NEMO_ERR_INVALID, "nemo_vertex_similarity: bad argument");
     hipLaunchKernelGGL(vertex_similarity_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, table, clu, boxes, m->V, H, W, out);
+    HIP_TRY(hipGetLastError());
+    return NEMO_OK;
+}
+
+// The same similarity straight from the feature maps: the vertex x pixel products are formed tile by tile on the matrix
+// cores and reduced to the per-pixel maximum over the vertices before anything is stored (table_gemm.hip).
+extern "C" size_t nemo_vertex_similarity_workspace(int32_t B, int32_t HW) {
+    if (B <= 0 || HW <= 0) return 0;
+    return align256(sizeof(float) * (size_t)B * ((HW + 127) / 128));
+}
+
+extern "C" int nemo_vertex_similarity_features(nemo_mesh_t m, const float* feat, const float* clu, const int32_t* boxes, int32_t B,
+                                               int32_t H, int32_t W, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B == 0) return NEMO_OK;
+    if (!m || !feat || !clu || !out || !workspace || B < 0 || H <= 0 || W <= 0)
+        return fail(NEMO_ERR_INVALID, "nemo_vertex_similarity_features: bad argument");
+    if (!m->memory) return fail(NEMO_ERR_STATE, "nemo_vertex_similarity_features: the mesh has no vertex memory");
+    if (!m->bank_frag)
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_vertex_similarity_features: %d channels (takes 16, 32, 64 or 128: use "
+                    "nemo_similarity_table + nemo_vertex_similarity)", m->C);
+    if (workspace_bytes < nemo_vertex_similarity_workspace(B, H * W))
+        return fail(NEMO_ERR_INVALID, "nemo_vertex_similarity_features: workspace of %zu bytes, %zu needed", workspace_bytes,
+                    nemo_vertex_similarity_workspace(B, H * W));
+    if (nemo::launch_vertex_max(m->bank_frag, feat, clu, boxes, m->V, m->C, H, W, B, (float*)workspace, out, (hipStream_t)stream))
+        return fail(NEMO_ERR_UNSUPPORTED, "nemo_vertex_similarity_features: batch too large for one launch");
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
 }

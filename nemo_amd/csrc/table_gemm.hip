@@ -148,6 +148,7 @@ int launch_table_gemm(const float* memT, const float* feat, float* table, int V,
 // ---------------------------------------------------------------------------------------------
 // split-f16 path
 // ---------------------------------------------------------------------------------------------
+int split_bank_blocks(int V);
 constexpr int SG_PT = 128;          // pixels per workgroup
 constexpr int SG_THREADS = 256;     // 4 waves, each a 32-vertex block x all 128 pixels at a time
 
@@ -355,6 +356,162 @@ __global__ __launch_bounds__(SG_THREADS) void split_table_kernel(const BankMeta*
         prev_v0 = vb * 32;
     }
     store_quads<0, 4, true>(w.tile, o, prev_v0, w.vg_n, w.lk, w.px, w.unscale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NeMo.fast_inference without the table (nemo/models/nemo.py:327-360):
+//   out[b] = mean over the pixels p of a box of max( max_v <memory[v], feat[b,:,p]>, clu[b,p] )
+// The same product as split_table_kernel (same operands, same instruction sequence per entry, so every vertex x
+// pixel value is what the table would hold), but a wave keeps only the running maximum over the vertices of each of
+// its pixels: 16 of a block's 32 rows sit in one lane's result registers, the other 16 in lane + 32.  The four waves'
+// maxima meet in LDS; nothing but one partial sum per (image, pixel tile) leaves the workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int NKS>
+__global__ __launch_bounds__(SG_THREADS) void vertex_max_kernel(const BankMeta* __restrict__ meta, const uint4* __restrict__ bank_frag,
+                                                                const float* __restrict__ feat, const float* __restrict__ clu,
+                                                                const int32_t* __restrict__ boxes, int V, int nvb, int H, int Wd, int npt,
+                                                                float* __restrict__ partial) {
+    extern __shared__ __align__(16) char sg_lds[];
+    using W = SplitWave<NKS>;
+    constexpr int C = W::C, row_bytes = W::row_bytes, piece_bytes = W::piece_bytes;
+    constexpr int WAVES = SG_THREADS / 64;
+    __shared__ float wmax[WAVES][SG_PT];
+    __shared__ float wsum[WAVES];
+    const int HW = H * Wd;
+    const int pt = blockIdx.x % npt, b = blockIdx.x / npt;
+    const int p0 = pt * SG_PT;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int r0 = 0, r1 = H, c0 = 0, c1 = Wd;
+    if (boxes) { r0 = max(boxes[4 * b], 0); r1 = min(boxes[4 * b + 1], H); c0 = max(boxes[4 * b + 2], 0); c1 = min(boxes[4 * b + 3], Wd); }
+    // a pixel tile that lies outside the box rows contributes nothing (uniform over the workgroup)
+    if (r1 <= r0 || c1 <= c0 || p0 >= r1 * Wd || p0 + SG_PT <= r0 * Wd) {
+        if (t == 0) partial[(size_t)b * npt + pt] = 0.0f;
+        return;
+    }
+    const float* fb = feat + (size_t)b * C * HW;
+    {       // feature tile -> f16 pieces in LDS, exactly as split_table_kernel's first phase
+        const int pl = t & (SG_PT - 1);
+        const int p = p0 + pl;
+        const bool pok = p < HW;
+        const float* col = fb + (pok ? p : HW - 1);
+        constexpr int KG_STEP = SG_THREADS / SG_PT, NKG = C / 8;
+        constexpr int NIT = (NKG + KG_STEP - 1) / KG_STEP;
+        float x[NIT][8];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int kg = t / SG_PT + it * KG_STEP;
+            const int kgc = kg < NKG ? kg : NKG - 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[it][j] = col[(size_t)(kgc * 8 + j) * HW];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int kg = t / SG_PT + it * KG_STEP;
+            if (kg < NKG) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[it][j] = pok ? scale_clamp(x[it][j]) : 0.0f;
+                uint4 pcs[SG_NP];
+                split8(x[it], pcs);
+#pragma unroll
+                for (int pc = 0; pc < SG_NP; ++pc)
+                    *reinterpret_cast<uint4*>(sg_lds + pc * piece_bytes + pl * row_bytes + kg * 16) = pcs[pc];
+            }
+        }
+    }
+    __syncthreads();
+    W w;
+    w.unscale = meta->unscale;
+    w.bank_frag = bank_frag; w.lane = lane; w.lk = lane >> 5; w.px = lane & 31;
+    w.bbase = sg_lds + (lane & 31) * row_bytes + w.lk * 16;
+    w.vg_n = (V + 3) >> 2;
+    w.tile = nullptr;
+    w.apiece = (size_t)nvb * NKS * 64;
+    float best[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) best[k] = -__builtin_inff();
+    const f32x16 none[4] = {};
+    for (int vb = wave; vb < nvb; vb += WAVES) {
+        f32x16 acc[4] = {};
+        w.template tile_mma<false>(vb, acc, none, 0);
+        // rows of this lane: vb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk; rows past V are padding (zero bank rows), not vertices
+        const int row0 = vb * 32 + 4 * w.lk;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool real = row0 + (i & 3) + 8 * (i >> 2) < V;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) best[k] = real ? max_nan(best[k], acc[k][i]) : best[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float other = __shfl_xor(best[k], 32);
+        best[k] = max_nan(best[k], other);
+        if (w.lk == 0) wmax[wave][k * 32 + w.px] = best[k];
+    }
+    __syncthreads();
+    float sum = 0.0f;
+    if (t < SG_PT) {
+        const int p = p0 + t;
+        const int y = p / Wd, x = p - y * Wd;
+        if (p < HW && y >= r0 && y < r1 && x >= c0 && x < c1) {
+            float m = wmax[0][t];
+#pragma unroll
+            for (int k = 1; k < WAVES; ++k) m = max_nan(m, wmax[k][t]);
+            sum = max_nan(m * w.unscale, clu[(size_t)b * HW + p]);          // the scale is a power of two: it commutes with the maximum
+        }
+    }
+    // fixed-order sum over the 128 pixel lanes (two waves), then over the two waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) wsum[wave] = sum;
+    __syncthreads();
+    if (t == 0) partial[(size_t)b * npt + pt] = wsum[0] + wsum[1];
+}
+
+// out[b] = (sum of the image's pixel-tile partial sums, in tile order) / number of box pixels
+__global__ void vertex_max_finalize_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boxes, int B, int H, int Wd,
+                                           int npt, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int r0 = 0, r1 = H, c0 = 0, c1 = Wd;
+    if (boxes) { r0 = max(boxes[4 * b], 0); r1 = min(boxes[4 * b + 1], H); c0 = max(boxes[4 * b + 2], 0); c1 = min(boxes[4 * b + 3], Wd); }
+    const int np = max(r1 - r0, 0) * max(c1 - c0, 0);
+    float s = 0.0f;
+    for (int k = 0; k < npt; ++k) s += partial[(size_t)b * npt + k];
+    out[b] = s / (float)np;          // an empty box: 0 / 0 = NaN, as the mean of an empty crop is in torch
+}
+
+template <int NKS>
+static void launch_vertex_max_nks(const void* buf, const float* feat, const float* clu, const int32_t* boxes, int V, int H, int Wd, int B,
+                                  int npt, float* partial, hipStream_t st) {
+    const BankMeta* meta = (const BankMeta*)buf;
+    const uint4* frag = (const uint4*)((const char*)buf + SG_META_BYTES);
+    constexpr int lds = SG_NP * SG_PT * (NKS * 16 * 2 + 16);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)vertex_max_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(vertex_max_kernel<NKS>, dim3((unsigned)(npt * B)), dim3(SG_THREADS), lds, st, meta, frag, feat, clu, boxes, V,
+                       split_bank_blocks(V), H, Wd, npt, partial);
+}
+
+// partial: B * ceil(H * W / 128) floats of scratch.
+int launch_vertex_max(const void* frag, const float* feat, const float* clu, const int32_t* boxes, int V, int C, int H, int Wd, int B,
+                      float* partial, float* out, hipStream_t st) {
+    const int npt = (H * Wd + SG_PT - 1) / SG_PT;
+    if ((long long)npt * B > 0x7FFFFFFFLL) return -1;
+    switch (C / 16) {
+        case 1: launch_vertex_max_nks<1>(frag, feat, clu, boxes, V, H, Wd, B, npt, partial, st); break;
+        case 2: launch_vertex_max_nks<2>(frag, feat, clu, boxes, V, H, Wd, B, npt, partial, st); break;
+        case 4: launch_vertex_max_nks<4>(frag, feat, clu, boxes, V, H, Wd, B, npt, partial, st); break;
+        case 8: launch_vertex_max_nks<8>(frag, feat, clu, boxes, V, H, Wd, B, npt, partial, st); break;
+        default: return -2;
+    }
+    hipLaunchKernelGGL(vertex_max_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const float*)partial, boxes, B, H, Wd, npt, out);
+    return 0;
 }
 
 bool split_table_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128; }

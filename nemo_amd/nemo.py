@@ -106,9 +106,9 @@ class NeMo:
         B, C, H, W = fm.shape
         boxes = torch.tensor([[int(float(bbox[i][0]) // 8), int(float(bbox[i][1]) // 8), int(float(bbox[i][2]) // 8),
                                int(float(bbox[i][3]) // 8)] for i in range(B)], dtype=torch.int32)
-        table = ops.similarity_table(self.inter_module.mesh, fm)
         clu = ops.clutter_score(fm, self.clutter_bank)
-        sim = ops.vertex_similarity(self.inter_module.mesh, table, clu, H, W, boxes)
+        # the vertex x pixel products are reduced to the per-pixel maximum inside the kernel: no [V, HW] table is written
+        sim = ops.vertex_similarity_from_features(self.inter_module.mesh, fm, clu, boxes)
         return [s for s in sim]
 
     # reference nemo.py:364-423

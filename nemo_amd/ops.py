@@ -448,6 +448,28 @@ def vertex_similarity(mesh, table, clu, H, W, boxes=None):
     return out
 
 
+def vertex_similarity_from_features(mesh, feature_map, clu, boxes=None):
+    """vertex_similarity without the table: feature_map [B,C,H,W], clu [B,H,W], boxes [B,4] int32 (r0,r1,c0,c1) or None
+    -> [B].  The vertex x pixel products are reduced to the per-pixel maximum inside the kernel; channel counts the
+    matrix-core form does not take (not 16 / 32 / 64 / 128) go through similarity_table + vertex_similarity."""
+    lib = _lib.load()
+    fm = f32c(feature_map)
+    B, Cc, H, W = fm.shape
+    if Cc != mesh.C:
+        raise ValueError("feature maps do not match the vertex memory")
+    if Cc not in (16, 32, 64, 128):
+        return vertex_similarity(mesh, similarity_table(mesh, fm), clu, H, W, boxes)
+    cl = f32c(clu).reshape(B, H * W)
+    out = torch.empty(B, device=fm.device)
+    bx = None if boxes is None else boxes.to(device=fm.device, dtype=torch.int32).contiguous()
+    nbytes = int(lib.nemo_vertex_similarity_workspace(B, H * W))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=fm.device)
+    with torch.cuda.device(fm.device):
+        check(lib.nemo_vertex_similarity_features(mesh.h, ptr(fm), ptr(cl), ptr(bx, torch.int32), B, H, W, ptr(out), ptr(ws, torch.uint8),
+                                                  nbytes, stream_ptr()), "nemo_vertex_similarity_features")
+    return out
+
+
 def align_maps(maps_source, distance_source, principal_source, target_shape, distance_target, principal_target,
                padding_mode="zeros"):
     """align_no_centered: maps_source [n,c,h1,w1] -> [n,c,h0,w0]; distances [n], principals [n,2] (x,y)."""

@@ -237,11 +237,23 @@ def test_similarity_table(full):
     clu = R.clutter_score(fm, sc.clutter)
     boxes = torch.tensor([[0, sc.H, 0, sc.W], [10, 50, 20, 90]], dtype=torch.int32)
     got = ops.vertex_similarity(sc.mod.mesh, tab, clu.to(sc.device), sc.H, sc.W, boxes)
+    # ... and straight from the feature maps (the form NeMo.fast_inference uses: no table is written)
+    fused = ops.vertex_similarity_from_features(sc.mod.mesh, fm.to(sc.device), clu.to(sc.device), boxes)
+    assert float((fused - got).abs().max()) < 1e-6
     for i in range(2):
         r0, r1, c0, c1 = boxes[i].tolist()
         m = fm[i][:, r0:r1, c0:c1].reshape(sc.C, -1)
         sim = torch.maximum((sc.mem @ m).max(dim=0)[0], (sc.clutter @ m).view(-1)).mean()
-        assert abs(float(got[i]) - float(sim)) < 1e-5
+        assert abs(float(got[i]) - float(sim)) < 1e-5 and abs(float(fused[i]) - float(sim)) < 1e-5
+    # boxes that start inside a pixel tile, end in the padding of the last one, or are empty; NaN features stay NaN
+    odd = torch.tensor([[3, 4, 97, 100], [79, 80, 0, 100], [40, 40, 10, 20]], dtype=torch.int32)
+    fm3 = torch.cat([fm, fm[:1]]).clone()
+    fm3[1, 7, 79, 50] = float("nan")
+    clu3 = R.clutter_score(fm3, sc.clutter)
+    tab3 = ops.similarity_table(sc.mod.mesh, fm3.to(sc.device))
+    a = ops.vertex_similarity(sc.mod.mesh, tab3, clu3.to(sc.device), sc.H, sc.W, odd)
+    b = ops.vertex_similarity_from_features(sc.mod.mesh, fm3.to(sc.device), clu3.to(sc.device), odd)
+    assert abs(float(a[0]) - float(b[0])) < 1e-6 and torch.isnan(a[1]) and torch.isnan(b[1]) and torch.isnan(a[2]) and torch.isnan(b[2])
 
 
 def test_grid_score_small(small):
