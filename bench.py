@@ -127,7 +127,10 @@ def _event_ms(fn, reps=3):
     return sorted(ts)[len(ts) // 2]
 
 
-def other_configs(dev, cfg, mod, clutter, maps, cs, ths, packed, batch=64):
+OTHER_CONFIGS = ("latency", "k8", "six_d", "classification", "clipped", "fast_inference")
+
+
+def other_configs(dev, cfg, mod, clutter, maps, cs, ths, packed, batch=64, which=OTHER_CONFIGS):
     """The other BASELINE configs on this GPU, a few calls each, through the drop-in entry points (not the headline's pipelined
     loop): every figure is one call at a time, median of three.  Returns the `other_configs` object of the JSON line."""
     import numpy as np
@@ -140,116 +143,122 @@ def other_configs(dev, cfg, mod, clutter, maps, cs, ths, packed, batch=64):
     fm64, _ = synthetic_images(mod, clutter, batch, first_seed=5000, dev=dev)
 
     # -- configs[1], one lone batch: what a caller of solve_pose waits for
-    med, mn = _median_ms(lambda: nemo_amd.solve_pose(cfg, fm64, mod, clutter, cs, ths, maps, device=dev), reps=5)
-    out["single_batch_latency_ms"] = {"median": med, "min": mn, "images": batch,
-                                      "call": "nemo_amd.solve_pose (clutter + 144-pose grid + complete table + 300 steps + read-out)"}
+    if "latency" in which:
+        med, mn = _median_ms(lambda: nemo_amd.solve_pose(cfg, fm64, mod, clutter, cs, ths, maps, device=dev), reps=5)
+        out["single_batch_latency_ms"] = {"median": med, "min": mn, "images": batch,
+                                          "call": "nemo_amd.solve_pose (clutter + 144-pose grid + complete table + 300 steps + read-out)"}
 
     # -- configs[2]: 8 starting poses per image (the 8 best grid poses), 128 images per call = 1024 hypotheses in one solve launch
-    n2 = 128
-    fm2 = torch.cat([fm64, synthetic_images(mod, clutter, n2 - batch, first_seed=5100, dev=dev)[0]]) if n2 > batch else fm64
-    med, _ = _median_ms(lambda: nemo_amd.solve_pose(cfg, fm2, mod, clutter, cs, ths, maps, device=dev, hypotheses=STRONG_HYPOTHESES))
-    t_tab = _event_ms(lambda: ops.similarity_table(mod.mesh, fm2))
-    out["configs[2] multi-hypothesis"] = {
-        "workload": f"{n2} images x {STRONG_HYPOTHESES} starting poses x {EPOCHS} steps per call (solve_pose(hypotheses=8)), one GPU",
-        "ms_per_call": med, "images_per_sec": n2 / med * 1e3, "hypothesis_steps_per_sec": n2 * STRONG_HYPOTHESES * EPOCHS / med * 1e3,
-        "dominant_kernel": "solve_kernel on the images' complete similarity tables (the 8 hypotheses of an image share it)",
-        "similarity_table_ms": t_tab,
-        "similarity_table_hbm_frac": n2 * 4.0 * math.prod(ops.table_shape(mod.mesh, 1, hw)) / (t_tab * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    del fm2
+    if "k8" in which:
+        n2 = 128
+        fm2 = torch.cat([fm64, synthetic_images(mod, clutter, n2 - batch, first_seed=5100, dev=dev)[0]]) if n2 > batch else fm64
+        med, _ = _median_ms(lambda: nemo_amd.solve_pose(cfg, fm2, mod, clutter, cs, ths, maps, device=dev, hypotheses=STRONG_HYPOTHESES))
+        t_tab = _event_ms(lambda: ops.similarity_table(mod.mesh, fm2))
+        out["configs[2] multi-hypothesis"] = {
+            "workload": f"{n2} images x {STRONG_HYPOTHESES} starting poses x {EPOCHS} steps per call (solve_pose(hypotheses=8)), one GPU",
+            "ms_per_call": med, "images_per_sec": n2 / med * 1e3, "hypothesis_steps_per_sec": n2 * STRONG_HYPOTHESES * EPOCHS / med * 1e3,
+            "dominant_kernel": "solve_kernel on the images' complete similarity tables (the 8 hypotheses of an image share it)",
+            "similarity_table_ms": t_tab,
+            "similarity_table_hbm_frac": n2 * 4.0 * math.prod(ops.table_shape(mod.mesh, 1, hw)) / (t_tab * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del fm2
 
     # -- configs[3]: 6-D, 576 poses (4 distances) x 25 principal-point samples, 64 images per call
-    cfg6 = default_pose3d_config()
-    cfg6.inference.dist_sample = ConfigNode({"min": 3.0, "max": 9.0, "num": 4})
-    cfg6.inference.px_sample = ConfigNode({"min": 0.25, "max": 0.75, "num": 5})
-    cfg6.inference.py_sample = ConfigNode({"min": 0.25, "max": 0.75, "num": 5})
-    az, el, th, di, px, py = get_param_samples(cfg6)
-    maps6, cs6, ths6 = nemo_amd.get_pre_render_samples(mod, az, el, th, di)
-    cand = torch.stack((torch.from_numpy(px).view(-1, 1).expand(-1, py.shape[0]) * W,
-                        torch.from_numpy(py).view(1, -1).expand(px.shape[0], -1) * H)).view(2, -1).T.float().to(dev)
-    call6 = lambda: nemo_amd.solve_pose(cfg6, fm64, mod, clutter, cs6, ths6, maps6, device=dev, principal=cand, dof=6)
-    med, _ = _median_ms(call6)
-    clu64 = ops.clutter_score(fm64, clutter)
-    t_init = _event_ms(lambda: bsp.initial_poses(fm64, clu64, mod.rasterizer.cameras, cs6, ths6, maps6, principal=cand, dof=6))
-    n_pose6, n_pr = int(cs6.shape[0]), int(cand.shape[0])
-    flops6 = 2.0 * batch * n_pr * n_pose6 * C * hw
-    out["configs[3] 6-D"] = {
-        "workload": f"{batch} images, {n_pose6}-pose grid x {n_pr} principal-point samples, then {EPOCHS} steps over 6 parameters "
-                    "(solve_pose(dof=6)), one GPU",
-        "ms_per_call": med, "images_per_sec": batch / med * 1e3,
-        "dominant_kernel": "grid scoring of the re-centred copies (grid_feat_recentred_kernel + grid_mfma_kernel)",
-        "dominant_kernel_ms": t_init,
-        "dominant_kernel_roofline": {"bound": "mfma", "achieved": flops6 / (t_init * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": flops6 / (t_init * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                                     "note": "useful flops 2 B P N C HW; three f16 piece products per useful one"}}
-    del maps6, cs6, ths6
+    if "six_d" in which:
+        cfg6 = default_pose3d_config()
+        cfg6.inference.dist_sample = ConfigNode({"min": 3.0, "max": 9.0, "num": 4})
+        cfg6.inference.px_sample = ConfigNode({"min": 0.25, "max": 0.75, "num": 5})
+        cfg6.inference.py_sample = ConfigNode({"min": 0.25, "max": 0.75, "num": 5})
+        az, el, th, di, px, py = get_param_samples(cfg6)
+        maps6, cs6, ths6 = nemo_amd.get_pre_render_samples(mod, az, el, th, di)
+        cand = torch.stack((torch.from_numpy(px).view(-1, 1).expand(-1, py.shape[0]) * W,
+                            torch.from_numpy(py).view(1, -1).expand(px.shape[0], -1) * H)).view(2, -1).T.float().to(dev)
+        call6 = lambda: nemo_amd.solve_pose(cfg6, fm64, mod, clutter, cs6, ths6, maps6, device=dev, principal=cand, dof=6)
+        med, _ = _median_ms(call6)
+        clu64 = ops.clutter_score(fm64, clutter)
+        t_init = _event_ms(lambda: bsp.initial_poses(fm64, clu64, mod.rasterizer.cameras, cs6, ths6, maps6, principal=cand, dof=6))
+        n_pose6, n_pr = int(cs6.shape[0]), int(cand.shape[0])
+        flops6 = 2.0 * batch * n_pr * n_pose6 * C * hw
+        out["configs[3] 6-D"] = {
+            "workload": f"{batch} images, {n_pose6}-pose grid x {n_pr} principal-point samples, then {EPOCHS} steps over 6 parameters "
+                        "(solve_pose(dof=6)), one GPU",
+            "ms_per_call": med, "images_per_sec": batch / med * 1e3,
+            "dominant_kernel": "grid scoring of the re-centred copies (grid_feat_recentred_kernel + grid_mfma_kernel)",
+            "dominant_kernel_ms": t_init,
+            "dominant_kernel_roofline": {"bound": "mfma", "achieved": flops6 / (t_init * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": flops6 / (t_init * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                         "note": "useful flops 2 B P N C HW; three f16 piece products per useful one"}}
+        del maps6, cs6, ths6
 
     # -- configs[4]: render-and-compare classification, 12 category cuboids in one multi-class bank, 128 images per call
-    n_cat, n4 = 12, 128
-    rng = np.random.RandomState(0)
-    meshes = []
-    for i in range(n_cat):
-        ex = 0.14 + 0.12 * rng.rand(3)
-        ex[1] += 0.15
-        v_, f_ = meshelize((-ex[0], ex[0]), (-ex[1], ex[1]), (-ex[2], ex[2]), 900 + 20 * i)
-        meshes.append((np.asarray(v_, dtype=np.float32), f_.astype(np.int32)))
-    counts = [m_[0].shape[0] for m_ in meshes]
-    g = torch.Generator().manual_seed(11)
-    bank = nemo_amd.FeatureBankNeMo(input_size=C, num_pos=sum(counts), num_noise=0, mesh_n_list=counts)
-    bank.load_memory(torch.nn.functional.normalize(torch.randn(sum(counts), C, generator=g), dim=1))
-    solver = nemo_amd.MultiCategorySolver(cfg, [f"cat{i}" for i in range(n_cat)], meshes, bank, clutter.cpu(), mod.rasterizer,
-                                          device=str(dev), dof=3)
-    fm4 = torch.cat([synthetic_images(solver.modules[i % n_cat], clutter, 1, first_seed=5200 + i, dev=dev)[0] for i in range(16)])
-    fm4 = fm4.repeat(n4 // 16, 1, 1, 1).contiguous()
-    res = {}
-    def call4():
-        res["names"], res["scores"], _ = solver.classify(fm4)
-    med, _ = _median_ms(call4)
-    right = sum(res["names"][i] == f"cat{(i % 16) % n_cat}" for i in range(n4))
-    out["configs[4] classification"] = {
-        "workload": f"{n4} images x {n_cat} category meshes ({min(counts)}-{max(counts)} vertices each, one multi-class bank): 144-pose "
-                    f"grid + {EPOCHS} steps per (image, category) pair, all {n4 * n_cat} pairs in one solve launch "
-                    "(MultiCategorySolver.classify), one GPU",
-        "ms_per_call": med, "images_per_sec": n4 / med * 1e3, "hypothesis_steps_per_sec": n4 * n_cat * EPOCHS / med * 1e3,
-        "correct_of_synthetic": f"{right}/{n4}",
-        "dominant_kernel": "solve_kernel with a mesh part per hypothesis (nemo_solve_features on the multi-mesh handle)"}
-    del solver, fm4
+    if "classification" in which:
+        n_cat, n4 = 12, 128
+        rng = np.random.RandomState(0)
+        meshes = []
+        for i in range(n_cat):
+            ex = 0.14 + 0.12 * rng.rand(3)
+            ex[1] += 0.15
+            v_, f_ = meshelize((-ex[0], ex[0]), (-ex[1], ex[1]), (-ex[2], ex[2]), 900 + 20 * i)
+            meshes.append((np.asarray(v_, dtype=np.float32), f_.astype(np.int32)))
+        counts = [m_[0].shape[0] for m_ in meshes]
+        g = torch.Generator().manual_seed(11)
+        bank = nemo_amd.FeatureBankNeMo(input_size=C, num_pos=sum(counts), num_noise=0, mesh_n_list=counts)
+        bank.load_memory(torch.nn.functional.normalize(torch.randn(sum(counts), C, generator=g), dim=1))
+        solver = nemo_amd.MultiCategorySolver(cfg, [f"cat{i}" for i in range(n_cat)], meshes, bank, clutter.cpu(), mod.rasterizer,
+                                              device=str(dev), dof=3)
+        fm4 = torch.cat([synthetic_images(solver.modules[i % n_cat], clutter, 1, first_seed=5200 + i, dev=dev)[0] for i in range(16)])
+        fm4 = fm4.repeat(n4 // 16, 1, 1, 1).contiguous()
+        res = {}
+        def call4():
+            res["names"], res["scores"], _ = solver.classify(fm4)
+        med, _ = _median_ms(call4)
+        right = sum(res["names"][i] == f"cat{(i % 16) % n_cat}" for i in range(n4))
+        out["configs[4] classification"] = {
+            "workload": f"{n4} images x {n_cat} category meshes ({min(counts)}-{max(counts)} vertices each, one multi-class bank): 144-pose "
+                        f"grid + {EPOCHS} steps per (image, category) pair, all {n4 * n_cat} pairs in one solve launch "
+                        "(MultiCategorySolver.classify), one GPU",
+            "ms_per_call": med, "images_per_sec": n4 / med * 1e3, "hypothesis_steps_per_sec": n4 * n_cat * EPOCHS / med * 1e3,
+            "correct_of_synthetic": f"{right}/{n4}",
+            "dominant_kernel": "solve_kernel with a mesh part per hypothesis (nemo_solve_features on the multi-mesh handle)"}
+        del solver, fm4
 
     # -- the full-size cuboid of a car (twice the headline's extents: it overflows the 100-pixel map at distance 5)
-    hx, hy, hz = HALF_EXTENTS
-    big, _, _, vb_, fb_ = build_scene(dev, half_extents=(2 * hx, 2 * hy, 2 * hz))
-    mapsb, csb, thsb = nemo_amd.get_pre_render_samples(big, *get_param_samples(cfg)[:4])
-    nb = 512
-    fmb = torch.cat([synthetic_images(big, clutter, batch, first_seed=5300 + batch * k, dev=dev)[0] for k in range(nb // batch)])
-    packedb = mapsb._nemo_packed_grid
-    wsb = torch.empty(ops.solve_workspace_bytes(big.mesh, nb, hw), dtype=torch.uint8, device=dev)
-    camb = big.camera()
-    def callb():
-        clu_, _, idx_, _ = ops.clutter_and_grid_score(fmb, clutter, packedb)
-        ops.solve_from_features(big.mesh, camb, fmb, clu_, csb[idx_.long()], thsb[idx_.long()], workspace=wsb, global_batch=batch,
-                                steps=EPOCHS, lr_every=EPOCHS // 3)
-    t_big = _event_ms(callb)
-    with torch.no_grad():
-        cov = float((mapsb.squeeze(1).abs().sum(dim=1) != 0).float().mean())
-    out["clipped-object scene"] = {
-        "workload": f"configs[1] with a cuboid of half extents {2 * hx}/{2 * hy}/{2 * hz} (V={vb_.shape[0]} F={fb_.shape[0]}): the object "
-                    f"overflows the map at distance 5 (mean coverage of the grid poses {cov:.2f} of the map), {nb} images in one launch",
-        "ms_per_launch": t_big, "images_per_sec": nb / t_big * 1e3, "hypothesis_steps_per_sec": nb * EPOCHS / t_big * 1e3}
-    del big, mapsb, fmb, wsb
+    if "clipped" in which:
+        hx, hy, hz = HALF_EXTENTS
+        big, _, _, vb_, fb_ = build_scene(dev, half_extents=(2 * hx, 2 * hy, 2 * hz))
+        mapsb, csb, thsb = nemo_amd.get_pre_render_samples(big, *get_param_samples(cfg)[:4])
+        nb = 512
+        fmb = torch.cat([synthetic_images(big, clutter, batch, first_seed=5300 + batch * k, dev=dev)[0] for k in range(nb // batch)])
+        packedb = mapsb._nemo_packed_grid
+        wsb = torch.empty(ops.solve_workspace_bytes(big.mesh, nb, hw), dtype=torch.uint8, device=dev)
+        camb = big.camera()
+        def callb():
+            clu_, _, idx_, _ = ops.clutter_and_grid_score(fmb, clutter, packedb)
+            ops.solve_from_features(big.mesh, camb, fmb, clu_, csb[idx_.long()], thsb[idx_.long()], workspace=wsb, global_batch=batch,
+                                    steps=EPOCHS, lr_every=EPOCHS // 3)
+        t_big = _event_ms(callb)
+        with torch.no_grad():
+            cov = float((mapsb.squeeze(1).abs().sum(dim=1) != 0).float().mean())
+        out["clipped-object scene"] = {
+            "workload": f"configs[1] with a cuboid of half extents {2 * hx}/{2 * hy}/{2 * hz} (V={vb_.shape[0]} F={fb_.shape[0]}): the object "
+                        f"overflows the map at distance 5 (mean coverage of the grid poses {cov:.2f} of the map), {nb} images in one launch",
+            "ms_per_launch": t_big, "images_per_sec": nb / t_big * 1e3, "hypothesis_steps_per_sec": nb * EPOCHS / t_big * 1e3}
+        del big, mapsb, fmb, wsb
 
     # -- NeMo.fast_inference: per-pixel maximum over the vertices of the bank x feature-map product, mean over the box
-    nf = 256
-    fmf = fm64.repeat(nf // batch, 1, 1, 1).contiguous()
-    def callf():
-        ops.vertex_similarity_from_features(mod.mesh, fmf, ops.clutter_score(fmf, clutter))
-    t_f = _event_ms(callf)
-    flops_f = 2.0 * nf * mod.mesh.V * C * hw
-    out["fast_inference"] = {
-        "workload": f"{nf} images, whole map as the box: clutter score + vertex-maximum similarity straight from the feature maps "
-                    "(no table written)",
-        "ms_per_call": t_f, "images_per_sec": nf / t_f * 1e3,
-        "roofline": {"bound": "mfma", "achieved": flops_f / (t_f * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops_f / (t_f * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                     "note": "useful flops 2 V C HW per image; three f16 piece products per useful one"}}
+    if "fast_inference" in which:
+        nf = 256
+        fmf = fm64.repeat(nf // batch, 1, 1, 1).contiguous()
+        def callf():
+            ops.vertex_similarity_from_features(mod.mesh, fmf, ops.clutter_score(fmf, clutter))
+        t_f = _event_ms(callf)
+        flops_f = 2.0 * nf * mod.mesh.V * C * hw
+        out["fast_inference"] = {
+            "workload": f"{nf} images, whole map as the box: clutter score + vertex-maximum similarity straight from the feature maps "
+                        "(no table written)",
+            "ms_per_call": t_f, "images_per_sec": nf / t_f * 1e3,
+            "roofline": {"bound": "mfma", "achieved": flops_f / (t_f * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops_f / (t_f * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                         "note": "useful flops 2 V C HW per image; three f16 piece products per useful one"}}
     return out
 
 
@@ -283,6 +292,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra measurements after the timed region (the other BASELINE configs, one lone batch, repeats)")
+    ap.add_argument("--other-configs", default=",".join(OTHER_CONFIGS),
+                    help="which of the extra measurements to run (comma list of " + ", ".join(OTHER_CONFIGS) + ")")
     ap.add_argument("--repeats", type=int, default=5, help="un-scored repetitions of the timed region reported as min / median")
     ap.add_argument("--no-stagger", action="store_true",
                     help="let the groups on different launch streams start together (default: a group's clutter / grid / table "
@@ -498,6 +509,9 @@ def main():
                   f"{trace_t0.elapsed_time(tr[1]):.2f} ms, solve ends {trace_t0.elapsed_time(tr[2]):.2f} ms", file=sys.stderr)
         print(f"trace: timed region {elapsed * 1e3:.2f} ms", file=sys.stderr)
     res = host_res[0][:B].clone()
+    if rank == 0 and os.environ.get("NEMO_BENCH_DUMP"):       # diagnostic: the gathered rows of the first group, rank-major
+        import numpy as np
+        np.save(os.environ["NEMO_BENCH_DUMP"], host_res[0].numpy())
     # the same region again (not scored): its spread
     rep_ms = []
     if not args.no_other_configs:
@@ -632,7 +646,7 @@ def main():
                        "clutter_score": "its own pass over the feature maps" if args.separate_clutter else "scored by the pass that builds the grid scoring's operand fragments (timed under grid_score)",
                        "hypotheses_per_image": K_HYP,
                        "partition": (f"images sharded over {world} GPU(s), all-gather of [B,7] results" if world > 1 else "single GPU") +
-                                    (" (process group: " + dist.get_backend() + ")" if grouped else "")},
+                                    (f" (process group: {dist.get_backend()}, world size {dist.get_world_size()})" if grouped else "")},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": n_hyp,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
             "roofline": {"kernel": "solve_kernel" if args.complete_table or args.no_bulk_tiles else
@@ -657,7 +671,8 @@ def main():
                               "median_value": n_hyp_steps / (srt[len(srt) // 2] * 1e-3),
                               "note": "the timed region run again after the scored one (same steps, same buffers), rank 0's clock"}
         if not args.no_other_configs and world == 1:
-            out["other_configs"] = other_configs(dev, cfg, mod, clutter, maps, cs, ths, packed, batch=B)
+            out["other_configs"] = other_configs(dev, cfg, mod, clutter, maps, cs, ths, packed, batch=B,
+                                                 which=tuple(x for x in args.other_configs.split(",") if x))
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(mod, mem, clutter, v, f, fm_g[0], pre, cs, ths)
         print(json.dumps(out))

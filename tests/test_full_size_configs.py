@@ -104,8 +104,10 @@ def test_six_dof_solve_full_size(gpu):
         assert abs(got["distance"] - float(fin[i, 3])) < 0.15, (got, fin[i])
         assert abs(got["principal"][0] - float(fin[i, 4])) < 0.2 and abs(got["principal"][1] - float(fin[i, 5])) < 0.2, (got, fin[i])
         assert abs(got["score"] - float(fin[i, 6])) < 2e-3
-        # and the answer is where the image was rendered: principal point within a pixel of the truth
-        assert abs(got["principal"][0] - float(gt_pr[i, 0])) < 1.0 and abs(got["principal"][1] - float(gt_pr[i, 1])) < 1.0
+    # image 0 is solved (principal point within a pixel of where it was rendered); image 1 starts from the wrong principal
+    # sample and ends in a local minimum, in the oracle as here: agreeing on that is part of the parity
+    assert abs(preds[0]["final"][0]["principal"][0] - float(gt_pr[0, 0])) < 1.0 and abs(preds[0]["final"][0]["principal"][1] - float(gt_pr[0, 1])) < 1.0
+    assert abs(float(fin[1, 4]) - float(gt_pr[1, 0])) > 5.0 and abs(preds[1]["final"][0]["principal"][0] - float(gt_pr[1, 0])) > 5.0
 
 
 @pytest.mark.parametrize("with_clutter", [True, False])
