@@ -116,6 +116,7 @@ def get_init_pos(inter_module, samples_pos, samples_theta, predicted_maps, clutt
         return samples_pos[idx], samples_theta[idx], torch.cat(mn)
 
 
+PER_CALL_COPIES = 2048           # re-centred copies (images x principal samples) scored per grid-scoring launch
 ON_DEMAND_MIN_IMAGES = 256       # from this many hypotheses per call on, the solve computes its similarity-table tiles itself
 
 
@@ -167,7 +168,7 @@ def initial_poses(feature_map, clutter_score, cameras, cam_pos_pre_rendered, the
     # copies are scored together, a few samples per grid-scoring launch, so the pre-rendered grid is
     # streamed once per launch instead of once per sample; results per sample are unchanged.
     all_C, all_theta, all_loss = [], [], []
-    per_call = max(1, 1024 // max(b, 1))
+    per_call = max(1, PER_CALL_COPIES // max(b, 1))
     packed = getattr(feature_pre_rendered, "_nemo_packed_grid", None)
     for s0 in range(0, principal.shape[0], per_call):
         chunk = principal[s0:s0 + per_call]

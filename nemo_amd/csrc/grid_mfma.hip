@@ -341,108 +341,6 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
     }
 }
 
-// The same scoring for grids of more than GM_RBG row blocks (the 6-D grid: 576 poses = 18 row blocks) in ONE pass over the
-// image fragments: a workgroup of four waves, one per SIMD, so that a wave may hold up to 512 registers: running sums of up
-// to 18 row blocks (288 registers), this pixel's image fragments and the next pixel's, requested a whole pixel ahead.
-// With the sliced form above the image fragments are read once per slice of six row blocks (three times for 576 poses).
-// NR is even (the LDS buffer a stage sits in is then known at compile time inside the loop over one pixel); a grid with an
-// odd number of row blocks skips its last stage.  Same instruction sequence per (pose, image, pixel) as grid_mfma_kernel
-// and the same partial-sum layout, so the losses are bit-identical to the sliced form's.
-constexpr int GW_WAVES = 4;
-
-template <int NKS, int NR>
-__global__ __launch_bounds__(64 * GW_WAVES) void grid_mfma_wide_kernel(const uint4* __restrict__ packed, const uint4* __restrict__ featp,
-                                                                      const float* __restrict__ clu, int N, int B, int HW, int nrb,
-                                                                      int ncb, int rb0, float unscale, float* __restrict__ partial) {
-    static_assert(NR % 2 == 0, "the stage -> LDS buffer map relies on an even number of stages per pixel");
-    constexpr int STAGE_U4 = NKS * 2 * 64;
-    constexpr int PER_THREAD = (STAGE_U4 + 64 * GW_WAVES - 1) / (64 * GW_WAVES);
-    __shared__ uint4 abuf[2][STAGE_U4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ncbg = (ncb + GW_WAVES - 1) / GW_WAVES;
-    const int chunk = ((int)blockIdx.x / 8 / ncbg) * 8 + (int)blockIdx.x % 8, cbg = ((int)blockIdx.x / 8) % ncbg;
-    if (chunk * GM_CHUNK >= HW) return;
-    const int cb = cbg * GW_WAVES + wave;
-    const bool wave_on = cb < ncb;
-    const int cbc = wave_on ? cb : ncb - 1;
-    const int b = cbc * 32 + (lane & 31), lk = lane >> 5;
-    const bool bvalid = wave_on && b < B;
-    const int p_begin = chunk * GM_CHUNK, p_end = min(p_begin + GM_CHUNK, HW);
-    const int npix = p_end - p_begin;
-    const int nr_real = min(NR, nrb - rb0);                       // row blocks of this slice that exist in the packed grid
-    const int nstage = npix * NR;
-
-    struct Staged { uint4 v[PER_THREAD]; };
-    auto fetch = [&](int st) {
-        Staged q = {};
-        const int r = st % NR;
-        if (r < nr_real) {
-            const uint4* src = packed + (((size_t)(p_begin + st / NR) * nrb + rb0 + r) * NKS) * 2 * 64;
-#pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GW_WAVES; if (e < STAGE_U4) q.v[i] = src[e]; }
-        }
-        return q;
-    };
-    auto park = [&](int buf, const Staged& q) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GW_WAVES; if (e < STAGE_U4) abuf[buf][e] = q.v[i]; }
-    };
-    struct ImageFrags { uint4 h[NKS], l[NKS]; float cl; };
-    auto load_image = [&](int pix) {
-        ImageFrags f;
-        const int p = p_begin + pix;
-        const uint4* bp = featp + (((size_t)p * ncb + cbc) * NKS) * 2 * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) { f.h[ks] = bp[(ks * 2 + 0) * 64]; f.l[ks] = bp[(ks * 2 + 1) * 64]; }
-        f.cl = (clu && bvalid) ? clu[(size_t)b * HW + p] : -__builtin_inff();
-        return f;
-    };
-
-    f32x16 lacc[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) lacc[r] = (f32x16){0};
-    Staged qa = {}, qb = {};
-    ImageFrags cur = load_image(0), nxt = cur;
-    qa = fetch(0); park(0, qa);
-    qb = fetch(1);
-    __syncthreads();
-    for (int pix = 0; pix < npix; ++pix) {
-        if (pix + 1 < npix) nxt = load_image(pix + 1);             // a whole pixel (NR stages of MFMAs) ahead of its use
-        const int st0 = pix * NR;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int st = st0 + r, buf = r & 1;                  // NR is even: stage st sits in buffer r & 1
-            if (st + 2 < nstage) { if (buf == 0) qa = fetch(st + 2); else qb = fetch(st + 2); }
-            if (r < nr_real) {
-                f32x16 S = {0};
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const f16x8 ah = as_frag(abuf[buf][(ks * 2 + 0) * 64 + lane]), al = as_frag(abuf[buf][(ks * 2 + 1) * 64 + lane]);
-                    const f16x8 bh = as_frag(cur.h[ks]), bl = as_frag(cur.l[ks]);
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, S, 0, 0, 0);
-                    S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, S, 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) lacc[r][i] += max_nan(S[i] * unscale, cur.cl);
-            }
-            if (st + 1 < nstage) { if (buf == 0) park(1, qb); else park(0, qa); }
-            __syncthreads();
-        }
-        cur = nxt;
-    }
-    if (!bvalid) return;
-    float* out = partial + ((size_t)chunk * B + b) * N;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int n = (rb0 + r) * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
-            if (r < nr_real && n < N) out[n] = lacc[r][i];
-        }
-    }
-}
-
 bool grid_mfma_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128; }
 int grid_chunks(int HW) { return (HW + GM_CHUNK - 1) / GM_CHUNK; }
 size_t grid_pack_bytes(int N, int C, int HW) { return (size_t)HW * ((N + 31) / 32) * (C / 16) * 2 * 64 * 16; }
@@ -466,43 +364,11 @@ static void launch_mfma_slice(const void* packed, const void* featp, const float
                        B, HW, nrb, ncb, rb0, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial);
 }
 
-template <int NKS, int NR>
-static void launch_mfma_wide(const void* packed, const void* featp, const float* clu, int N, int B, int HW, int rb0, float* partial,
-                             hipStream_t st) {
-    const int nrb = (N + 31) / 32, ncb = (B + 31) / 32;
-    const dim3 grid((unsigned)(((grid_chunks(HW) + 7) / 8) * 8 * ((ncb + GW_WAVES - 1) / GW_WAVES)));
-    hipLaunchKernelGGL((grid_mfma_wide_kernel<NKS, NR>), grid, dim3(64 * GW_WAVES), 0, st, (const uint4*)packed, (const uint4*)featp, clu,
-                       N, B, HW, nrb, ncb, rb0, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial);
-}
-
-// Grids of more than GM_RBG row blocks with 32 or 128 channels: up to 18 row blocks per pass over the image fragments.
-constexpr int GW_RBG = 18;
-template <int NKS>
-static bool launch_mfma_wide_nks(const void* packed, const void* featp, const float* clu, int N, int B, int HW, float* partial,
-                                 hipStream_t st) {
-    if (NKS != 2 && NKS != 8) return false;
-    const int nrb = (N + 31) / 32;
-    if (nrb <= GM_RBG) return false;
-    if constexpr (NKS == 2 || NKS == 8) {
-        for (int rb0 = 0; rb0 < nrb; rb0 += GW_RBG) {
-            const int left = nrb - rb0;
-            if (left <= 8) launch_mfma_wide<NKS, 8>(packed, featp, clu, N, B, HW, rb0, partial, st);
-            else if (left <= 10) launch_mfma_wide<NKS, 10>(packed, featp, clu, N, B, HW, rb0, partial, st);
-            else if (left <= 12) launch_mfma_wide<NKS, 12>(packed, featp, clu, N, B, HW, rb0, partial, st);
-            else if (left <= 14) launch_mfma_wide<NKS, 14>(packed, featp, clu, N, B, HW, rb0, partial, st);
-            else if (left <= 16) launch_mfma_wide<NKS, 16>(packed, featp, clu, N, B, HW, rb0, partial, st);
-            else launch_mfma_wide<NKS, 18>(packed, featp, clu, N, B, HW, rb0, partial, st);
-        }
-    }
-    return true;
-}
-
 // All row blocks of the grid, GM_RBG at a time (one launch per slice; 144 poses are one slice).
 template <int NKS>
 static void launch_mfma_nks(const void* packed, const void* featp, const float* clu, int N, int B, int HW, float* partial,
                             hipStream_t st) {
     const int nrb = (N + 31) / 32;
-    if (launch_mfma_wide_nks<NKS>(packed, featp, clu, N, B, HW, partial, st)) return;
     for (int rb0 = 0; rb0 < nrb; rb0 += GM_RBG) {
         switch (nrb - rb0 < GM_RBG ? nrb - rb0 : GM_RBG) {
             case 1: launch_mfma_slice<NKS, 1>(packed, featp, clu, N, B, HW, rb0, partial, st); break;
