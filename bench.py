@@ -572,7 +572,7 @@ def main():
         traffic = valu = grid_mfma_busy = None
         import glob
         counters, exact = None, False
-        for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_solve_counters*.json")), reverse=True):
+        for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]_solve_counters*.json")), reverse=True):
             with open(cpath) as fh:
                 cj = json.load(fh)
             if cj.get("adam_steps") != EPOCHS or cj.get("on_demand_table") != (not args.complete_table):
@@ -626,6 +626,30 @@ def main():
                             "note": "useful flops 2 B N C HW; the two-piece f16 operands cost three matrix-core products per useful one, and the "
                                     "time includes the pass that turns the feature maps into operand fragments (and, unless --separate-clutter, "
                                     "scores the clutter vectors) and the finalize pass"}
+        # The solve call is bound by vector-instruction issue and by the latencies between its barriers, not by HBM: the
+        # primary figure is the issue rate (when the counter profile of this launch shape is at hand), the HBM figure the
+        # secondary one.
+        hbm_roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": solve_algo,
+                    "note": "algorithmic bytes of the implemented design: 300 steps x covered pixels x 16 B (three table entries + clutter "
+                            "score per covered pixel) + computed table tiles x 4 KB + touched pixel tiles x 16 KB of feature map + the "
+                            "bank operand, / the launch time measured with HIP events on the launch stream"}
+        roof = {"kernel": "solve_kernel" if args.complete_table or args.no_bulk_tiles else
+                          "solve_kernel (the solve call: the loop, the launch that lists its first step's tiles and tile_bulk_kernel)"}
+        if valu is not None:
+            roof.update({"bound": "valu_issue", "achieved": valu["wave_instructions_per_launch"] / (solve_ms * 1e-3) / 1e9,
+                         "peak": valu["peak_per_sec"] / 1e9, "unit": "G wave-instructions/s", "frac": valu["frac"],
+                         "model": valu["model"], "source": valu["source"], "hbm": hbm_roof})
+        else:
+            roof.update(hbm_roof)
+        roof.update({"traffic": traffic, "traffic_source": traffic_source,
+                     "census": {"covered_pixels_per_step": covered, "table_tiles_computed": tiles, "pixel_tiles_touched": pixel_tiles,
+                                "table_fraction_computed": None if tiles is None else tiles * 1024 / (n_img * math.prod(ops.table_shape(mod.mesh, 1, H * W)))},
+                     "note": "bound = the resource that limits the kernel: vector-instruction issue (SQ_INSTS_VALU of the committed counter "
+                             "pass of this launch shape / the launch time measured here / 256 CUs x 4 SIMDs x clock / 2 cycles per "
+                             "wave-instruction); the rest of the time is barriers, one-lane sections and LDS / gather latency. `hbm` is "
+                             "the same launch against the HBM roofline on the implemented design's algorithmic bytes; `traffic` the "
+                             "fabric-side bytes per launch from the FETCH_SIZE + WRITE_SIZE passes"})
         hx, hy, hz = HALF_EXTENTS
         out = {
             "metric": "pose_opt_steps_per_sec", "value": n_hyp_steps / elapsed, "unit": "hypothesis-steps/s",
@@ -649,19 +673,7 @@ def main():
                                     (f" (process group: {dist.get_backend()}, world size {dist.get_world_size()})" if grouped else "")},
             "kernel_ms_per_launch": dict(kern_ms), "hypotheses_per_launch": n_hyp,
             "median_pose_error_deg_vs_synthetic_gt": med_err,
-            "roofline": {"kernel": "solve_kernel" if args.complete_table or args.no_bulk_tiles else
-                                   "solve_kernel (the solve call: the loop, the launch that lists its first step's tiles and tile_bulk_kernel)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": solve_algo,
-                         "census": {"covered_pixels_per_step": covered, "table_tiles_computed": tiles, "pixel_tiles_touched": pixel_tiles,
-                                    "table_fraction_computed": None if tiles is None else tiles * 1024 / (n_img * math.prod(ops.table_shape(mod.mesh, 1, H * W)))},
-                         "traffic_source": traffic_source,
-                         "valu_issue": valu,
-                         "note": "algorithmic bytes of the implemented design: 300 steps x covered pixels x 16 B (three table entries + clutter "
-                                 "score per covered pixel) + computed table tiles x 4 KB + touched pixel tiles x 16 KB of feature map + the "
-                                 "bank operand, / measured launch time.  The kernel is bound by vector issue and LDS latency, not by HBM: "
-                                 "see valu_issue"},
+            "roofline": roof,
             "speedup_vs_streaming_design": n_hyp * EPOCHS * STREAM_BYTES_PER_HYP_STEP / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "front_kernel_rooflines": other,
         }
