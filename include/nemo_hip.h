@@ -106,9 +106,10 @@ int nemo_render(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, c
 
 /* forward_interpolate with mode='nearest' (nemo/utils/mesh.py:59-70,104-109): the same rasterisation, but a covered
  * pixel takes the feature of the face's vertex with the largest barycentric coordinate (the first one on ties, as
- * argmax picks it) instead of the barycentric blend.  Forward only: the reference's backward of this mode is a
- * straight-through softmax over the barycentrics, which nothing on the solver path uses.  The reference forms the
- * weight of that vertex as softmax + (1 - softmax) in f32, which is 1 or 1 - 2^-24; here it is exactly 1. */
+ * argmax picks it) instead of the barycentric blend.  The reference forms the weight of that vertex as
+ * softmax + (1 - softmax) in f32, which is 1 or 1 - 2^-24; here it is exactly 1.  Its backward
+ * (nemo_render_nearest_backward) is the reference's straight-through estimator: the gradient w.r.t. the
+ * barycentrics is that of softmax(barycentrics). */
 int nemo_render_nearest(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos, const float* theta,
                         const float* principal, int32_t n, float* out_maps, void* stream);
 
@@ -120,6 +121,13 @@ int nemo_render_backward(nemo_mesh_t mesh, const nemo_camera* cam, const float* 
                          const float* theta, const float* principal, int32_t n,
                          const float* grad_maps, float* grad_campos, float* grad_theta,
                          float* grad_principal, void* stream);
+/* The same for maps rendered by nemo_render_nearest (mode='nearest', nemo/utils/mesh.py:59-70): the weights are
+ * softmax(b) + (one_hot - softmax(b)).detach(), so the gradient reaches the barycentrics b through the softmax's
+ * Jacobian, gb_j <- s_j (gb_j - sum_i gb_i s_i), and then takes the same chain to the camera. */
+int nemo_render_nearest_backward(nemo_mesh_t mesh, const nemo_camera* cam, const float* campos,
+                                 const float* theta, const float* principal, int32_t n,
+                                 const float* grad_maps, float* grad_campos, float* grad_theta,
+                                 float* grad_principal, void* stream);
 
 /* ---- clutter score -------------------------------------------------------------------------
  * batch_solve_pose.py:214-225: 1x1 conv of the feature map with each clutter vector, max over

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NEMO_HIP_LIB") or os.path.join(_HERE, "libnemo_hip.so
 # every symbol include/nemo_hip.h declares
 SYMBOLS = [
     "nemo_last_error", "nemo_version", "nemo_mesh_create", "nemo_mesh_set_memory", "nemo_mesh_destroy",
-    "nemo_mesh_info", "nemo_mesh_set_parts", "nemo_solve_parts", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_clutter_score", "nemo_align_maps",
+    "nemo_mesh_info", "nemo_mesh_set_parts", "nemo_solve_parts", "nemo_project", "nemo_render", "nemo_render_backward", "nemo_render_nearest_backward", "nemo_clutter_score", "nemo_align_maps",
     "nemo_grid_score_workspace", "nemo_grid_score", "nemo_grid_score_static", "nemo_grid_pack_bytes", "nemo_grid_pack",
     "nemo_grid_score_packed_workspace", "nemo_grid_score_packed", "nemo_clutter_grid_score_packed", "nemo_grid_fragments_bytes", "nemo_grid_score_fragments_workspace", "nemo_grid_score_fragments", "nemo_grid_score_recentred_workspace",
     "nemo_grid_score_recentred", "nemo_similarity_table_elems", "nemo_similarity_table", "nemo_vertex_similarity",
@@ -58,6 +58,7 @@ def load():
     lib.nemo_project.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, f32p, f32p, vp]
     lib.nemo_render.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, f32p, vp, f32p, f32p, vp]
     lib.nemo_render_backward.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, f32p, f32p, f32p, f32p, vp]
+    lib.nemo_render_nearest_backward.argtypes = [vp, C.POINTER(NemoCamera), f32p, f32p, f32p, i32, f32p, f32p, f32p, f32p, vp]
     lib.nemo_clutter_score.argtypes = [f32p, f32p, i32, i32, i32, i32, f32p, vp]
     lib.nemo_grid_score_workspace.argtypes = [i32, i32, i32]
     lib.nemo_grid_score_workspace.restype = C.c_size_t

@@ -564,6 +564,7 @@ struct RenderBwdArgs {
     float def_px, def_py;
     const float* grad_maps;
     float* g_campos; float* g_theta; float* g_principal;
+    int nearest;        // the maps were rendered with mode='nearest': the gradient passes through a softmax over the barycentrics
 };
 
 template <bool FL>
@@ -600,6 +601,18 @@ __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderB
             const float* mt = a.memory_t + (size_t)c * V;
             gb[0] += g * mt[i0]; gb[1] += g * mt[i1]; gb[2] += g * mt[i2];
         }
+        if (a.nearest) {
+            // mode='nearest' (nemo/utils/mesh.py:59-70): the weights are softmax(b) + (one_hot - softmax(b)).detach(), so
+            // the gradient w.r.t. the barycentrics is that of the softmax: gb_j <- s_j (gb_j - sum_i gb_i s_i)
+            float bb[3], pz;
+            face_eval(fv, s.xs[xi], s.ys[yi], bb, &pz);
+            const float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
+            const float e0 = expf(bb[0] - mx), e1 = expf(bb[1] - mx), e2 = expf(bb[2] - mx);
+            const float inv = 1.0f / ((e0 + e1) + e2);
+            const float s0 = e0 * inv, s1 = e1 * inv, s2 = e2 * inv;
+            const float dot = (gb[0] * s0 + gb[1] * s1) + gb[2] * s2;
+            gb[0] = s0 * (gb[0] - dot); gb[1] = s1 * (gb[1] - dot); gb[2] = s2 * (gb[2] - dot);
+        }
         float X0[3], X1[3], X2[3];
         view_coords(vinv, fv, X0, X1, X2);
         pixel_backward(a.rc.cc, fv, X0, X1, X2, s.xs[xi], s.ys[yi], gb, &acc);
@@ -617,9 +630,9 @@ __global__ __launch_bounds__(kRasterThreads) void render_backward_kernel(RenderB
     }
 }
 
-extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
-                                    const float* principal, int32_t n, const float* grad_maps, float* g_campos,
-                                    float* g_theta, float* g_principal, void* stream) {
+static int render_backward_impl(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                const float* principal, int32_t n, const float* grad_maps, float* g_campos,
+                                float* g_theta, float* g_principal, int nearest, void* stream) {
     if (n == 0) return NEMO_OK;
     if (!m || !campos || !theta || !grad_maps || n < 0) return fail(NEMO_ERR_INVALID, "nemo_render_backward: bad argument");
     if (check_cam(cam)) return NEMO_ERR_INVALID;
@@ -633,11 +646,24 @@ extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const
     a.memory_t = m->memory_t; a.C = m->C;
     a.campos = campos; a.theta = theta; a.principal = principal; a.def_px = cam->px; a.def_py = cam->py;
     a.grad_maps = grad_maps; a.g_campos = g_campos; a.g_theta = g_theta; a.g_principal = g_principal;
+    a.nearest = nearest;
     auto kern = a.rc.L.faces >= 0 ? render_backward_kernel<true> : render_backward_kernel<false>;
     if (set_lds_limit(kern, a.rc.L.total)) return NEMO_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(n), dim3(kRasterThreads), a.rc.L.total, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return NEMO_OK;
+}
+
+extern "C" int nemo_render_backward(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                    const float* principal, int32_t n, const float* grad_maps, float* g_campos,
+                                    float* g_theta, float* g_principal, void* stream) {
+    return render_backward_impl(m, cam, campos, theta, principal, n, grad_maps, g_campos, g_theta, g_principal, 0, stream);
+}
+
+extern "C" int nemo_render_nearest_backward(nemo_mesh_t m, const nemo_camera* cam, const float* campos, const float* theta,
+                                            const float* principal, int32_t n, const float* grad_maps, float* g_campos,
+                                            float* g_theta, float* g_principal, void* stream) {
+    return render_backward_impl(m, cam, campos, theta, principal, n, grad_maps, g_campos, g_theta, g_principal, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ Several meshes at once (lists of vertices / faces / memory banks, reference :110
 camera i renders mesh i (or the one camera renders every mesh); each mesh has its own handle and launch.
 
 Not supported (raise): the VoGE variant (needs the un-vendored VoGE package), blur_radius > 0,
-faces_per_pixel > 1, the backward of mode='nearest', off_set_mesh / deform_verts.
+faces_per_pixel > 1, off_set_mesh / deform_verts.
 """
 import torch
 import torch.nn as nn
@@ -33,10 +33,10 @@ def MeshInterpolateModule(*args, **kwargs):
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, campos, theta, principal, module):
+    def forward(ctx, campos, theta, principal, module, nearest=False):
         cam = module.camera()
-        out = ops.render(module.mesh, cam, campos, theta, principal, maps=True)["maps"]
-        ctx.module, ctx.cam = module, cam
+        out = ops.render(module.mesh, cam, campos, theta, principal, maps=True, nearest=nearest)["maps"]
+        ctx.module, ctx.cam, ctx.nearest = module, cam, nearest
         ctx.save_for_backward(campos.detach(), theta.detach(), None if principal is None else principal.detach())
         ctx.shapes = (campos.shape, theta.shape, None if principal is None else principal.shape)
         return out
@@ -46,12 +46,12 @@ class _RenderFn(torch.autograd.Function):
         campos, theta, principal = ctx.saved_tensors
         want_p = principal is not None and ctx.needs_input_grad[2]
         gC, gT, gP = ops.render_backward(ctx.module.mesh, ctx.cam, campos, theta, principal, grad_maps.contiguous(),
-                                         want_principal=want_p)
+                                         want_principal=want_p, nearest=ctx.nearest)
         gP_out = None
         if want_p:
             gP_out = gP if ctx.shapes[2][0] == gP.shape[0] else gP.sum(dim=0, keepdim=True)
             gP_out = gP_out.reshape(ctx.shapes[2])
-        return gC.reshape(ctx.shapes[0]), gT.reshape(ctx.shapes[1]), gP_out, None
+        return gC.reshape(ctx.shapes[0]), gT.reshape(ctx.shapes[1]), gP_out, None, None
 
 
 class MeshInterpolateModuleMesh(nn.Module):
@@ -156,16 +156,12 @@ class MeshInterpolateModuleMesh(nn.Module):
             raise ValueError(f"unknown interpolation mode {mode!r}")
         if deform_verts is not None:
             raise NotImplementedError("deform_verts is not supported")
-        if mode == "nearest":       # forward only (nemo/utils/mesh.py:59-70)
-            if torch.is_grad_enabled() and (campos.requires_grad or theta.requires_grad or (principal is not None and principal.requires_grad)):
-                raise NotImplementedError("mode='nearest' is forward only here: render under torch.no_grad() or with detached poses")
-            return ops.render(self.mesh, self.camera(), campos.detach(), theta.detach(),
-                              None if principal is None else principal.detach(), maps=True, nearest=True)["maps"]
         needs_grad = torch.is_grad_enabled() and (campos.requires_grad or theta.requires_grad or (
             principal is not None and principal.requires_grad))
+        nearest = mode == "nearest"         # nemo/utils/mesh.py:59-70; its backward is the straight-through softmax
         if needs_grad:
-            return _RenderFn.apply(campos, theta, principal, self)
-        return ops.render(self.mesh, self.camera(), campos, theta, principal, maps=True)["maps"]
+            return _RenderFn.apply(campos, theta, principal, self, nearest)
+        return ops.render(self.mesh, self.camera(), campos, theta, principal, maps=True, nearest=nearest)["maps"]
 
     def rasterize(self, campos, theta):
         """Fragments of the same rasterisation: pix_to_face [n,H,W] int64 (packed index i*F + f as

@@ -26,14 +26,24 @@ from .mesh_interpolate_module import MeshInterpolateModuleMesh
 from .utils import get_param_samples
 
 
+def _shape_only(maps):
+    """A tensor of maps' shape without its storage (one element, stride 0) that carries maps' packed grid: what the solver
+    passes where the reference passes feature_pre_rendered once the f32 maps themselves are not needed any more."""
+    stand_in = torch.zeros(1, device=maps.device, dtype=maps.dtype).expand(maps.shape)
+    stand_in._nemo_packed_grid = maps._nemo_packed_grid
+    stand_in._nemo_shape_only = True
+    return stand_in
+
+
 class MultiCategorySolver:
     """categories: names; meshes: [(vertices [V_i,3], faces [F_i,3])] in the bank's order; memory_bank: a
     FeatureBankNeMo built with mesh_n_list (or anything with .memory_pos / .vertex_block(i)); clutter_bank [K, C];
     rasterizer: the shared MeshRasterizer (camera + raster settings); dof 3 or 6 (`principal_samples` [P, 2] in
-    feature-map pixels for dof 6)."""
+    feature-map pixels for dof 6); keep_f32_grids: keep the pre-rendered f32 maps beside their packed form (`grids[i][0]`
+    is otherwise a storage-free stand-in that only carries the packed grid)."""
 
     def __init__(self, cfg, categories, meshes, memory_bank, clutter_bank, rasterizer, device="cuda:0", dof=3,
-                 principal_samples=None):
+                 principal_samples=None, keep_f32_grids=False):
         if len(categories) != len(meshes) or not categories:
             raise ValueError("one mesh per category")
         self.cfg, self.categories, self.dof = cfg, list(categories), int(dof)
@@ -55,6 +65,11 @@ class MultiCategorySolver:
         self.mesh.set_parts(counts, [int(m.faces.shape[0]) for m in self.modules])
         az, el, th, di, _, _ = get_param_samples(cfg)
         self.grids = [get_pre_render_samples(m, az, el, th, di) for m in self.modules]
+        if not keep_f32_grids:
+            # the scoring reads the packed (matrix-core) form only: drop the f32 maps (590 MB per category at 80 x 100 x 128) and
+            # keep a storage-free stand-in of the same shape that carries the packed grid
+            self.grids = [(_shape_only(maps), cs, ths) if getattr(maps, "_nemo_packed_grid", None) is not None else (maps, cs, ths)
+                          for maps, cs, ths in self.grids]
         self.principal_samples = None if principal_samples is None else torch.as_tensor(principal_samples).float().to(self.device)
         if self.dof == 6 and self.principal_samples is None:
             raise ValueError("dof 6 needs principal_samples")

@@ -182,8 +182,9 @@ def render(mesh, cam, campos, theta, principal=None, maps=True, fragments=False,
     return out
 
 
-def render_backward(mesh, cam, campos, theta, principal, grad_maps, want_principal=False):
-    """-> (grad_campos [n,3], grad_theta [n], grad_principal [n,2] or None)."""
+def render_backward(mesh, cam, campos, theta, principal, grad_maps, want_principal=False, nearest=False):
+    """-> (grad_campos [n,3], grad_theta [n], grad_principal [n,2] or None).  nearest: the maps came from render(..., nearest=True)
+    (mode='nearest'): the gradient passes through the softmax over the barycentrics (the reference's straight-through estimator)."""
     lib = _lib.load()
     cp, th, pr, n = _pose_args(campos, theta, principal)
     gm = f32c(grad_maps)
@@ -194,8 +195,9 @@ def render_backward(mesh, cam, campos, theta, principal, grad_maps, want_princip
     gP = torch.empty(n, 2, device=cp.device) if want_principal else None
     cc = cam.c()
     with torch.cuda.device(cp.device):
-        check(lib.nemo_render_backward(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, ptr(gm), ptr(gC), ptr(gT),
-                                       ptr(gP), stream_ptr()), "nemo_render_backward")
+        fn = lib.nemo_render_nearest_backward if nearest else lib.nemo_render_backward
+        check(fn(mesh.h, C.byref(cc), ptr(cp), ptr(th), ptr(pr), n, ptr(gm), ptr(gC), ptr(gT), ptr(gP), stream_ptr()),
+              "nemo_render_nearest_backward" if nearest else "nemo_render_backward")
     return gC, gT, gP
 
 
@@ -270,6 +272,8 @@ def grid_score(pre_rendered, feature_map, clutter_score_map=None, packed=None):
                                              ptr(amin, torch.int32), ptr(mn), ptr(ws, torch.uint8), nbytes, stream_ptr()),
                   "nemo_grid_score_packed")
         return loss, amin, mn
+    if getattr(pre_rendered, "_nemo_shape_only", False):
+        raise ValueError("these pre-rendered maps were dropped after packing (a shape-only stand-in): pass packed=")
     pre = f32c(pre_rendered)
     N, Cc, H, W = pre.shape
     if tuple(fm.shape[1:]) != (Cc, H, W):

@@ -170,16 +170,32 @@ def gen_full_grid():
     print("oracle_full_grid.npz written")
 
 
-def gen_full_solves():
-    """BASELINE configs[4] and [3] at full size: what MultiCategorySolver.classify and solve_pose(dof=6) are checked against."""
+def gen_full_solves(parts=("cls", "six")):
+    """BASELINE configs[4] and [3] at full size: what MultiCategorySolver.classify and solve_pose(dof=6) are checked against.
+    parts: which half to (re)compute; the other half is kept from the existing file."""
+    path = os.path.join(GOLD, "oracle_full_solves.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    if "cls" in parts:
+        out = {k: v for k, v in out.items() if not k.startswith("cls_")}
+        out.update(_gen_full_classification())
+    if "six" in parts:
+        out = {k: v for k, v in out.items() if not k.startswith("six_")}
+        out.update(_gen_full_six_dof())
+    np.savez_compressed(path, **out)
+    print("oracle_full_solves.npz written")
+
+
+def _gen_full_classification():
     out = {}
-    # --- classification: nemo_cls.py:262-282 - every image solved against every category mesh, smallest final loss wins
-    n_cat, labels, first_seed = 12, (3, 8), 700
+    # --- classification: nemo_cls.py:262-282 - every image solved against every category mesh, smallest final loss wins.
+    # Image seeds chosen so that the solve with the image's own category settles within the 300 steps (seed 701 of category 8
+    # is still sliding down at step 299, in the oracle as on the GPU: its final loss then depends on rounding in step 30).
+    n_cat, labels, seeds = 12, (3, 8), (700, 703)
     meshes, counts, mem, clutter = categories(n_cat, 128, number_vertices=full_size_vertex_counts, n_clutter=2560)
     cam = R.Camera(80, 100, 375.0)
     offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
     refs = [R.MeshInterpolateModuleRef(v, f, mem[o:o + c], cam) for (v, f), o, c in zip(meshes, offs, counts)]
-    fm = torch.stack([R.synthetic_feature_map(refs[lab], clutter, first_seed + i)[0] for i, lab in enumerate(labels)])
+    fm = torch.stack([R.synthetic_feature_map(refs[lab], clutter, seed)[0] for seed, lab in zip(seeds, labels)])
     az, el, th, di, _, _ = R.get_param_samples(GRID_CFG)
     scores, poses, init_idx = np.zeros((2, n_cat), np.float32), np.zeros((2, n_cat, 4), np.float32), np.zeros((2, n_cat), np.int64)
     for c in range(n_cat):
@@ -191,8 +207,13 @@ def gen_full_solves():
             poses[i, c] = (f["azimuth"], f["elevation"], f["theta"], f["distance"])
         init_idx[:, c] = info["init_idx"].numpy()
         print("category", c, scores[:, c], flush=True)
-    out.update(cls_labels=np.array(labels), cls_first_seed=np.int64(first_seed), cls_scores=scores, cls_poses=poses,
+    out.update(cls_labels=np.array(labels), cls_seeds=np.array(seeds), cls_scores=scores, cls_poses=poses,
                cls_init_idx=init_idx, cls_argmin=scores.argmin(axis=1))
+    return out
+
+
+def _gen_full_six_dof():
+    out = {}
     # --- 6-D: batch_solve_pose.py:264-338 with dof 6 (the images and candidates of the grid fixture's 6-D slice)
     sc = Scene(80, 100, 128, 1000, 375.0, n_clutter=2560)
     az6, el6, th6, di6, _, _ = R.get_param_samples(CFG6D)
@@ -211,8 +232,7 @@ def gen_full_solves():
                six_solve_final=fin, six_solve_use=info["init_idx"].numpy(), six_solve_init_C=info["init_C"].numpy(),
                six_solve_init_theta=info["init_theta"].numpy())
     print("6-D solve", fin, flush=True)
-    np.savez_compressed(os.path.join(GOLD, "oracle_full_solves.npz"), **out)
-    print("oracle_full_solves.npz written")
+    return out
 
 
 if __name__ == "__main__":
@@ -229,3 +249,7 @@ if __name__ == "__main__":
         gen_full_grid()
     if "solves" in what:
         gen_full_solves()
+    if "solves_cls" in what:
+        gen_full_solves(("cls",))
+    if "solves_six" in what:
+        gen_full_solves(("six",))

@@ -392,7 +392,7 @@ def set_bary_coords_to_nearest(bary):
     flat = bary.reshape(-1, shape[-1])
     target = torch.zeros_like(flat).scatter(1, flat.argmax(1).unsqueeze(1), 1.0)
     soft = torch.softmax(flat, dim=1)
-    return (soft + (target - soft)).view(*shape) + exr
+    return (soft + (target - soft).detach()).view(*shape) + exr      # straight-through: the gradient is the softmax's
 
 
 class MeshInterpolateModuleRef:

@@ -46,9 +46,9 @@ def test_classification_twelve_categories_full_size(gpu):
     offs = bank.mesh_offsets()
     labels = [int(x) for x in gold["cls_labels"]]
     fms = []
-    for i, lab in enumerate(labels):
+    for seed, lab in zip(gold["cls_seeds"], labels):
         ref = R.MeshInterpolateModuleRef(meshes[lab][0], meshes[lab][1], mem[offs[lab]:offs[lab] + counts[lab]], cam)
-        fms.append(R.synthetic_feature_map(ref, clutter, int(gold["cls_first_seed"]) + i)[0])
+        fms.append(R.synthetic_feature_map(ref, clutter, int(seed))[0])
     fm = torch.stack(fms)
     names, scores, preds = solver.classify(fm.to(gpu))
     ref_scores, ref_poses = gold["cls_scores"], gold["cls_poses"]

@@ -352,6 +352,34 @@ def test_render_backward_matches_autograd(small):
     assert rel_err(td.grad, t.grad) < 1e-3
 
 
+def test_nearest_mode_backward_matches_autograd(small):
+    """mode='nearest' is differentiable in the reference through its straight-through estimator (nemo/utils/mesh.py:59-70:
+    weights softmax(b) + (one_hot - softmax(b)).detach()): the gradient reaches the pose through the softmax of the
+    barycentrics.  nemo_render_nearest_backward against autograd through the oracle's restatement."""
+    sc = small
+    fm, _ = sc.feature_maps(3, first_seed=30)
+    clu = R.clutter_score(fm, sc.clutter)
+    campos, theta = random_poses(3, seed=23, dist=(4.5, 5.5))
+    C = campos.clone().requires_grad_(True)
+    t = theta.clone().requires_grad_(True)
+    loss = R.loss_fg_bg(torch.sum(sc.ref(C, t, mode="nearest") * fm, dim=1), clu)
+    loss.backward()
+    Cd = campos.clone().to(sc.device).requires_grad_(True)
+    td = theta.clone().to(sc.device).requires_grad_(True)
+    obj = torch.sum(sc.mod(Cd, td, mode="nearest") * fm.to(sc.device), dim=1)
+    cl = clu.to(sc.device)
+    lossd = 1 - (torch.max(obj, cl).mean() - cl.mean())
+    lossd.backward()
+    assert abs(float(lossd.detach()) - float(loss.detach())) < REL * abs(float(loss.detach()))
+    assert float(C.grad.abs().max()) > 0 and rel_err(Cd.grad, C.grad) < 1e-3 and rel_err(td.grad, t.grad) < 1e-3
+    # it is not the bilinear mode's gradient
+    Cb = campos.clone().to(sc.device).requires_grad_(True)
+    tb = theta.clone().to(sc.device).requires_grad_(True)
+    objb = torch.sum(sc.mod(Cb, tb) * fm.to(sc.device), dim=1)
+    (1 - (torch.max(objb, cl).mean() - cl.mean())).backward()
+    assert rel_err(Cb.grad, Cd.grad) > 1e-2
+
+
 def _solve_both(sc, B, epochs, dof=3, first_seed=0, perturb=0.0):
     from nemo_amd import ops
     fm, gts = sc.feature_maps(B, first_seed)
