@@ -95,6 +95,12 @@ def _image_index(hyp_to_image, n_img, device):
     return hyp_to_image.to(device=device, dtype=torch.int32).contiguous()
 
 
+def _rows(t, n, width):
+    """t as contiguous f32 [n, -1]; with n == 0 (where -1 is ambiguous to torch) [0, width]."""
+    t = f32c(t)
+    return t.reshape(0, width) if n == 0 else t.reshape(n, -1).contiguous()
+
+
 def _pose_args(campos, theta, principal):
     cp = f32c(campos).reshape(-1, 3)
     n = cp.shape[0]
@@ -363,6 +369,11 @@ def grid_score_static(pre_rendered, feature_map, clutter_score_map, out_loss, ou
     return out_loss, out_argmin, out_min
 
 
+def grid_mfma_channels(c):
+    """Channel counts the matrix-core grid scoring (and with it the re-centred scoring) takes."""
+    return c in (16, 32, 64, 128)
+
+
 def grid_score_recentred(packed, feature_map, clutter_score_map, dist_src, dist_tgt, p_src, p_tgt, padding_mode="border"):
     """Scores re-centred copies of a batch against a packed grid without materialising them.
     feature_map [B,C,h1,w1], clutter_score_map [B,h1,w1] or None; dist_src / dist_tgt [nv], p_src / p_tgt [nv,2]
@@ -376,13 +387,17 @@ def grid_score_recentred(packed, feature_map, clutter_score_map, dist_src, dist_
     if padding_mode not in ("zeros", "border"):
         raise NotImplementedError("padding_mode must be 'zeros' or 'border'")
     nv = int(dist_src.numel())
-    args = [f32c(t.to(fm.device)).reshape(nv, -1).contiguous() for t in (dist_src, dist_tgt, p_src, p_tgt)]
+    args = [_rows(t.to(fm.device), nv, w) for t, w in ((dist_src, 1), (dist_tgt, 1), (p_src, 2), (p_tgt, 2))]
     if args[2].shape[1] != 2 or args[3].shape[1] != 2:
         raise ValueError("p_src / p_tgt must be [nv, 2]")
     clu = None if clutter_score_map is None else f32c(clutter_score_map).reshape(B, h1 * w1)
     loss = torch.empty(nv, N, device=fm.device)
     amin = torch.empty(nv, dtype=torch.int32, device=fm.device)
     mn = torch.empty(nv, device=fm.device)
+    if not grid_mfma_channels(Cc):
+        raise NotImplementedError(f"grid_score_recentred takes 16, 32, 64 or 128 channels, not {Cc}")
+    if nv == 0:
+        return loss, amin, mn
     nbytes = lib.nemo_grid_score_recentred_workspace(N, nv, Cc, h0, w0)
     if nbytes == 0:
         raise NotImplementedError(f"grid_score_recentred takes 16, 32, 64 or 128 channels, not {Cc}")
@@ -483,8 +498,8 @@ def align_maps(maps_source, distance_source, principal_source, target_shape, dis
     h0, w0 = int(target_shape[0]), int(target_shape[1])
     if padding_mode not in ("zeros", "border"):
         raise NotImplementedError("padding_mode must be 'zeros' or 'border'")
-    args = [f32c(t.to(src.device)).reshape(n, -1).contiguous() for t in (distance_source, distance_target, principal_source,
-                                                                         principal_target)]
+    args = [_rows(t.to(src.device), n, w) for t, w in ((distance_source, 1), (distance_target, 1), (principal_source, 2),
+                                                       (principal_target, 2))]
     out = torch.empty(n, c, h0, w0, device=src.device)
     with torch.cuda.device(src.device):
         check(lib.nemo_align_maps(ptr(src), ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), n, c, h1, w1, h0, w0,
@@ -504,7 +519,7 @@ def solve(mesh, cam, table, clu, init_campos, init_theta, init_principal=None, h
     if hyp_to_image is None and n_hyp != n_img:
         raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
     h2i = _image_index(hyp_to_image, n_img, cp.device)
-    clu2 = f32c(clu).reshape(n_img, -1)
+    clu2 = _rows(clu, n_img, cam.H * cam.W)
     if tuple(table.shape) != table_shape(mesh, n_img, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
         raise ValueError("table / clutter shapes do not match the mesh and camera")
     opt = NemoAdam(int(steps), int(lr_every if lr_every is not None else max(steps // 3, 0)), float(lr), float(betas[0]),
@@ -550,7 +565,7 @@ def solve_from_features(mesh, cam, feature_map, clu, init_campos, init_theta, in
     if hyp_to_image is None and n_hyp != n_img:
         raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
     h2i = _image_index(hyp_to_image, n_img, cp.device)
-    clu2 = f32c(clu).reshape(n_img, -1)
+    clu2 = _rows(clu, n_img, H * W)
     if clu2.shape[1] != H * W:
         raise ValueError("clutter score map does not match the camera")
     nbytes = solve_workspace_bytes(mesh, n_img, H * W)
@@ -649,7 +664,7 @@ def solve_flow(mesh, cam, table, clu, init_campos, init_theta, init_flow=None, h
     if hyp_to_image is None and n_hyp != n_img:
         raise ValueError("hyp_to_image is required when the number of hypotheses differs from the number of images")
     h2i = _image_index(hyp_to_image, n_img, cp.device)
-    clu2 = f32c(clu).reshape(n_img, -1)
+    clu2 = _rows(clu, n_img, cam.H * cam.W)
     if tuple(table.shape) != table_shape(mesh, n_img, cam.H * cam.W) or not table.is_contiguous() or clu2.shape[1] != cam.H * cam.W:
         raise ValueError("table / clutter shapes do not match the mesh and camera")
     opt = NemoAdam(int(steps), int(lr_every), float(lr), float(betas[0]), float(betas[1]), float(eps), float(lr_gamma))

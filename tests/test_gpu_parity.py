@@ -94,6 +94,54 @@ def test_degenerate_and_empty(small):
     assert e["maps"].shape[0] == 0
 
 
+def test_zero_sized_inputs(small):
+    """No images, no hypotheses, no steps: every entry point returns results of the right (empty) shape and launches
+    nothing, the drop-in solve_pose returns no poses; a pose grid without poses has no arg-min and is refused."""
+    import nemo_amd
+    from nemo_amd import ops
+    from nemo_amd.utils import default_pose3d_config, get_param_samples
+    sc, dev = small, small.device
+    mesh, cam, HW = sc.mod.mesh, sc.mod.camera(), sc.H * sc.W
+    campos, theta = (t.to(dev) for t in random_poses(4, seed=1))
+    fm = torch.randn(2, sc.C, sc.H, sc.W, generator=torch.Generator().manual_seed(3)).to(dev)
+    clutter = torch.randn(1, sc.C, generator=torch.Generator().manual_seed(4)).to(dev)
+    none = fm[:0]
+    pre = ops.render(mesh, cam, campos, theta)["maps"]
+    packed = ops.grid_pack(pre)
+    assert ops.project(mesh, cam, campos[:0], theta[:0])[1].shape[0] == 0
+    assert ops.project_keypoints(mesh, cam, campos[:0], theta[:0])[0].shape[0] == 0
+    assert ops.clutter_score(none, clutter).shape == (0, sc.H, sc.W)
+    loss, amin, mn = ops.grid_score(pre, none, None)
+    assert loss.shape == (0, 4) and amin.shape == (0,) and mn.shape == (0,)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.grid_score(pre[:0], fm, None)
+    clu0, loss, amin, mn = ops.clutter_and_grid_score(none, clutter, packed)
+    assert clu0.shape == (0, sc.H, sc.W) and loss.shape == (0, 4)
+    z1, z2 = torch.ones(0, device=dev), torch.zeros(0, 2, device=dev)
+    clu = ops.clutter_score(fm, clutter)
+    loss, amin, mn = ops.grid_score_recentred(packed, fm, clu, z1, z1, z2, z2)
+    assert loss.shape == (0, 4) and amin.shape == (0,)
+    assert ops.align_maps(none, z1, z2, (sc.H, sc.W), z1, z2).shape == (0, sc.C, sc.H, sc.W)
+    tab0 = ops.similarity_table(mesh, none)
+    assert tab0.shape == ops.table_shape(mesh, 0, HW)
+    assert ops.vertex_similarity_from_features(mesh, none, clu[:0]).shape == (0,)
+    tab = ops.similarity_table(mesh, fm)
+    no_hyp = torch.zeros(0, dtype=torch.int32, device=dev)
+    assert ops.solve(mesh, cam, tab, clu, campos[:0], theta[:0], hyp_to_image=no_hyp, steps=3)[0].shape == (0, 8)
+    assert ops.solve_from_features(mesh, cam, fm, clu, campos[:0], theta[:0], hyp_to_image=no_hyp, steps=3)[0].shape == (0, 8)
+    assert ops.solve(mesh, cam, tab0, clu[:0], campos[:0], theta[:0], steps=3)[0].shape == (0, 8)
+    # no steps: the pose comes back as it went in, with the score of one forward
+    pose, _ = ops.solve(mesh, cam, tab, clu, campos[:2], theta[:2], steps=0)
+    assert torch.equal(pose[:, 0:3], campos[:2]) and torch.equal(pose[:, 3], theta[:2])
+    cfg = default_pose3d_config()
+    az, el, th, di, _, _ = get_param_samples(cfg)
+    maps, cs, ths = nemo_amd.get_pre_render_samples(sc.mod, az, el, th, di)
+    assert nemo_amd.solve_pose(cfg, none, sc.mod, clutter, cs, ths, maps) == []
+    two = torch.tensor([[25.0, 20.0], [27.0, 21.0]], device=dev)
+    assert nemo_amd.solve_pose(cfg, none, sc.mod, clutter, cs, ths, maps, dof=6, principal=two) == []
+    torch.cuda.synchronize()
+
+
 def test_largest_maps_and_size_limits(gpu):
     """Largest maps.  The bit-exact renderer keeps 64-bit keys and a pair queue in LDS: with the 1118-vertex mesh
     it takes up to about 11 k pixels (96 x 112 here); the optimisation loop (32-bit keys) takes 128 x 128 = a
