@@ -1331,7 +1331,13 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         STAMP(0);
         if (verts_resident) project_vertices_resident(rc, s, wv); else project_vertices(rc, s);
         STAMP(1);
+        // The rasterise phase goes ahead of the other hypothesis's waves on this compute unit (whose other phases wait on LDS and
+        // gathers most of the time): two workgroups that start together otherwise move through their phases side by side and
+        // compete for the same resource in each.  Launches of one or two full rounds of workgroups take 5 % less time with
+        // it (512 hypotheses 9.0 -> 8.5 ms, 1024: 16.7 -> 15.8); launches whose last round is partly empty are unchanged.
+        __builtin_amdgcn_s_setprio(1);
         raster_direct<FL>(rc, s);
+        __builtin_amdgcn_s_setprio(0);
 #ifdef NEMO_STAMPS_P1
         if (tid == 0 && a.out_hist) for (int k = 0; k < 6; ++k) a.out_hist[(size_t)h * a.steps + 16 + k] += s.tot[k] / (float)a.steps;
 #endif
