@@ -262,11 +262,15 @@ print("ok", rank)
 
 
 def test_two_process_gather_gloo(tmp_path):
+    import socket
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:     # a port nobody listens on, for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2

@@ -11,11 +11,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (for the rendezvous of the launched ranks)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
+
+
 @pytest.mark.gpu
 def test_bench_single_rank_rccl_group():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8", "--in-flight", "2", "--steps", "4",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8", "--in-flight", "2", "--steps", "4",
            "--warmup", "2", "--no-cpu-baseline", "--no-other-configs"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -37,7 +45,7 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     dump = str(tmp_path / "rows.npy")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", NEMO_BENCH_REHEARSAL="1", NEMO_BENCH_DUMP=dump)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--in-flight", "1", "--steps", "2",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--in-flight", "1", "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
