@@ -179,7 +179,11 @@ int nemo_grid_score_static(const float* pre, const float* feat, const float* clu
  * into pixel-major fragment order; every call then converts the batch's feature maps to the same
  * order inside the workspace and runs one [N x C].[C x B] product per pixel.  C must be 16, 32, 64 or
  * 128 (nemo_grid_pack_bytes returns 0 otherwise: use nemo_grid_score).
- * packed: device buffer of nemo_grid_pack_bytes(N, C, HW) bytes, filled by nemo_grid_pack.
+ * packed: device buffer of nemo_grid_pack_bytes(N, C, HW) bytes, filled by nemo_grid_pack: the fragments and, behind
+ * them, one bit per pixel = "some pose has a non-zero value here".  With a clutter map a pixel no pose covers is not
+ * multiplied: it adds max(0, clu) to every loss, which is what the product of its all-zero fragments gives (bit-identical
+ * sums).  The clutter map is expected to be the score of the same feature maps (a NaN feature at such a pixel then
+ * reaches the losses through its NaN clutter score); without a clutter map every pixel is multiplied.
  * Outputs as nemo_grid_score; workspace of nemo_grid_score_packed_workspace(N, B, C, HW) bytes.
  * Input contract of the matrix-core forms (this one, nemo_grid_score_recentred and nemo_similarity_table for 16, 32,
  * 64 or 128 channels): feature values of magnitude up to 255 (the backbone's maps are unit vectors per pixel,

@@ -7,7 +7,8 @@
 // the reduction.  Both operands are kept pixel-major in MFMA fragment order as two-piece f16 values
 // (split_f16.h), so a wave reads each fragment as one contiguous kilobyte:
 //
-//   packed grid   [p][row block of 32 poses][k-step of 16 channels][piece][lane]   built once per grid
+//   packed grid   [p][row block of 32 poses][k-step of 16 channels][piece][lane]   built once per grid,
+//                 followed by one bit per pixel: some pose covers it (grid_mask_kernel)
 //   feature frags [p][column block of 32 images][k-step][piece][lane]              built once per batch
 //
 // A wave owns one column block (32 images) and walks the pixels of its chunk; for every pixel and row
@@ -47,6 +48,32 @@ __global__ __launch_bounds__(256) void grid_pack_kernel(const float* __restrict_
     const size_t base = (((size_t)p * nrb + rb) * nks + ks) * 2;
     packed[(base + 0) * 64 + lane] = pcs[0];
     packed[(base + 1) * 64 + lane] = pcs[1];
+}
+
+// Behind the packed fragments: one bit per pixel = some pose of the grid has a non-zero value there (any channel).  A pixel
+// no pose covers contributes max(0, clutter) to every loss (its pose fragments are all zero), which the scoring adds
+// without reading anything.  One workgroup per 64 pixels, its four waves share the rows (pose x channel) of the maps.
+__global__ __launch_bounds__(256) void grid_mask_kernel(const float* __restrict__ pre, unsigned int* __restrict__ mask, int rows, int HW) {
+    __shared__ unsigned int found[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    if (threadIdx.x < 2) found[threadIdx.x] = 0u;
+    __syncthreads();
+    bool any = false;
+    if (p < HW) {
+        for (int r0 = wave; r0 < rows; r0 += 4 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 4 * u;
+                if (r < rows) any |= pre[(size_t)r * HW + p] != 0.0f;        // true for NaN as well
+            }
+            if (__all(any)) break;
+        }
+    }
+    const unsigned long long m = __ballot(any);
+    if (lane == 0) { atomicOr(&found[0], (unsigned int)m); atomicOr(&found[1], (unsigned int)(m >> 32)); }
+    __syncthreads();
+    if (threadIdx.x < 2 && blockIdx.x * 2 + threadIdx.x < (unsigned)((HW + 31) / 32)) mask[blockIdx.x * 2 + threadIdx.x] = found[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,7 +285,9 @@ constexpr int GM_WAVES = 8;
 template <int NKS, int NR>
 __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* __restrict__ packed, const uint4* __restrict__ featp,
                                                                  const float* __restrict__ clu, int N, int B, int HW, int nrb,
-                                                                 int ncb, int rb0, float unscale, float* __restrict__ partial) {
+                                                                 int ncb, int rb0, float unscale, float* __restrict__ partial,
+                                                                 const unsigned int* __restrict__ covered) {
+    static_assert(GM_CHUNK == 32, "one word of the coverage mask per chunk");
     constexpr int STAGE_U4 = NKS * 2 * 64;                       // uint4 per stage
     constexpr int PER_THREAD = (STAGE_U4 + 64 * GM_WAVES - 1) / (64 * GM_WAVES);
     __shared__ uint4 abuf[2][STAGE_U4];
@@ -275,12 +304,21 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
     const int b = cbc * 32 + (lane & 31), lk = lane >> 5;
     const bool bvalid = wave_on && b < B;
     const int p_begin = chunk * GM_CHUNK, p_end = min(p_begin + GM_CHUNK, HW);
-    const int nstage = (p_end - p_begin) * NR;
+    // The pixels of the chunk that go through the matrix cores, as a bit mask (uniform over the workgroup): all of them, or,
+    // with a clutter map, the ones some pose of the grid covers.  Without a clutter map nothing is skipped: a NaN feature at
+    // a pixel no pose covers must still reach the sums (0 x NaN), with one it does through its clutter score.
+    const int npx_all = p_end - p_begin;
+    unsigned int px_mask = npx_all >= 32 ? 0xFFFFFFFFu : ((1u << npx_all) - 1u);
+    if (covered && clu) px_mask &= (unsigned int)__builtin_amdgcn_readfirstlane((int)covered[chunk]);
+    const int nstage = __popc(px_mask) * NR;
+    unsigned int fetch_left = px_mask, work_left = px_mask;     // pixels not yet fetched / multiplied (their lowest bit is next)
+    int fetch_px = 0, work_px = -1;                             // offsets in the chunk of the pixel being fetched / multiplied
 
     struct Staged { uint4 v[PER_THREAD]; };                      // one thread's share of a stage, held in registers
     Staged qa = {}, qb = {};                                     // register sets 0 and 1
-    auto fetch = [&](int st) {
-        const uint4* src = packed + (((size_t)(p_begin + st / NR) * nrb + rb0 + st % NR) * NKS) * 2 * 64;
+    auto fetch = [&](int st) {                                   // called for st = 0, 1, 2, ... in this order
+        if (st % NR == 0) { fetch_px = __ffs((int)fetch_left) - 1; fetch_left &= fetch_left - 1u; }
+        const uint4* src = packed + (((size_t)(p_begin + fetch_px) * nrb + rb0 + st % NR) * NKS) * 2 * 64;
         Staged q = {};
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) { const int e = tid + i * 64 * GM_WAVES; if (e < STAGE_U4) q.v[i] = src[e]; }
@@ -296,6 +334,17 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
     for (int r = 0; r < NR; ++r) lacc[r] = (f32x16){0};
     f16x8 bh[NKS], bl[NKS];
     float cl = -__builtin_inff();
+    // pixels [from, to) of the chunk that no pose covers: what the matrix instructions would return for them is +0
+    auto uncovered = [&](int from, int to) {
+        for (int q = from; q < to; ++q) {
+            const float cq = bvalid ? clu[(size_t)b * HW + p_begin + q] : -__builtin_inff();
+            const float v = max_nan(0.0f * unscale, cq);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) lacc[r][i] += v;
+        }
+    };
 
     if (nstage > 0) { qa = fetch(0); park(0, qa); }
     if (nstage > 1) qb = fetch(1);
@@ -309,7 +358,11 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
             // stage st is in LDS buffer `buf`; register set 1 - buf holds stage st + 1; set `buf` is free
             if (st + 2 < nstage) { if (buf == 0) qa = fetch(st + 2); else qb = fetch(st + 2); }
             if (r == 0) {                                        // new pixel: this wave's image fragments
-                const int p = p_begin + st / NR;
+                const int nxt = __ffs((int)work_left) - 1;
+                work_left &= work_left - 1u;
+                if (nxt > work_px + 1) uncovered(work_px + 1, nxt);      // the sums take the pixels in ascending order
+                work_px = nxt;
+                const int p = p_begin + nxt;
                 const uint4* bp = featp + (((size_t)p * ncb + cbc) * NKS) * 2 * 64 + lane;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) { bh[ks] = as_frag(bp[(ks * 2 + 0) * 64]); bl[ks] = as_frag(bp[(ks * 2 + 1) * 64]); }
@@ -329,6 +382,7 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
             __syncthreads();
         }
     }
+    if (work_px + 1 < npx_all) uncovered(work_px + 1, npx_all);
     if (!bvalid) return;
     float* out = partial + ((size_t)chunk * B + b) * N;
 #pragma unroll
@@ -343,7 +397,9 @@ __global__ __launch_bounds__(64 * GM_WAVES) void grid_mfma_kernel(const uint4* _
 
 bool grid_mfma_supported(int C) { return C == 16 || C == 32 || C == 64 || C == 128; }
 int grid_chunks(int HW) { return (HW + GM_CHUNK - 1) / GM_CHUNK; }
-size_t grid_pack_bytes(int N, int C, int HW) { return (size_t)HW * ((N + 31) / 32) * (C / 16) * 2 * 64 * 16; }
+static size_t grid_pack_fragment_bytes(int N, int C, int HW) { return (size_t)HW * ((N + 31) / 32) * (C / 16) * 2 * 64 * 16; }
+static size_t grid_mask_bytes(int HW) { return (((size_t)(HW + 31) / 32) * 4 + 15) & ~(size_t)15; }
+size_t grid_pack_bytes(int N, int C, int HW) { return grid_pack_fragment_bytes(N, C, HW) + grid_mask_bytes(HW); }
 size_t grid_feat_bytes(int B, int C, int HW) { return (size_t)HW * ((B + 31) / 32) * (C / 16) * 2 * 64 * 16; }
 
 int launch_grid_pack(const float* pre, void* packed, int N, int C, int HW, hipStream_t st) {
@@ -352,6 +408,8 @@ int launch_grid_pack(const float* pre, void* packed, int N, int C, int HW, hipSt
     const long long nwg = (total + 255) / 256;
     if (nwg > 0x7FFFFFFFLL) return -1;
     hipLaunchKernelGGL(grid_pack_kernel, dim3((unsigned)nwg), dim3(256), 0, st, pre, (uint4*)packed, N, C, HW, nrb);
+    hipLaunchKernelGGL(grid_mask_kernel, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, st, pre,
+                       (unsigned int*)((char*)packed + grid_pack_fragment_bytes(N, C, HW)), N * C, HW);
     return 0;
 }
 
@@ -360,8 +418,9 @@ static void launch_mfma_slice(const void* packed, const void* featp, const float
                               hipStream_t st) {
     const int nrb = (N + 31) / 32, ncb = (B + 31) / 32;
     const dim3 grid((unsigned)(((grid_chunks(HW) + 7) / 8) * 8 * ((ncb + GM_WAVES - 1) / GM_WAVES)));
+    const unsigned int* covered = (const unsigned int*)((const char*)packed + grid_pack_fragment_bytes(N, NKS * 16, HW));
     hipLaunchKernelGGL((grid_mfma_kernel<NKS, NR>), grid, dim3(64 * GM_WAVES), 0, st, (const uint4*)packed, (const uint4*)featp, clu, N,
-                       B, HW, nrb, ncb, rb0, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial);
+                       B, HW, nrb, ncb, rb0, 1.0f / (SG_FEAT_SCALE * SG_FEAT_SCALE), partial, covered);
 }
 
 // All row blocks of the grid, GM_RBG at a time (one launch per slice; 144 poses are one slice).

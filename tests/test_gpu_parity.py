@@ -142,6 +142,38 @@ def test_zero_sized_inputs(small):
     torch.cuda.synchronize()
 
 
+def test_grid_scoring_skips_uncovered_pixels_exactly(full):
+    """A pixel no pose of the grid covers has all-zero pose fragments; the matrix-core scoring adds its max(0, clutter)
+    without multiplying.  Bit-equal to the same grid with a value too small for the f16 pieces (1e-30) put at every such
+    pixel of one map: identical fragments, every pixel marked covered, every pixel multiplied."""
+    from nemo_amd import ops
+    sc = full
+    campos, theta = random_poses(40, seed=11, dist=(4.5, 5.5))
+    pre = ops.render(sc.mod.mesh, sc.mod.camera(), campos.to(sc.device), theta.to(sc.device))["maps"]
+    uncovered = pre.abs().sum(dim=(0, 1)) == 0
+    assert 0.1 < float(uncovered.float().mean()) < 0.9
+    forced = pre.clone()
+    forced[0, 0][uncovered] = 1e-30
+    packed, packed_forced = ops.grid_pack(pre), ops.grid_pack(forced)
+    fm, _ = sc.feature_maps(3, 40)
+    fm = fm.to(sc.device)
+    clutter = sc.clutter.to(sc.device)
+    a = ops.clutter_and_grid_score(fm, clutter, packed)
+    b = ops.clutter_and_grid_score(fm, clutter, packed_forced)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    clu = ops.clutter_score(fm, clutter)
+    assert torch.equal(ops.grid_score(None, fm, clu, packed=packed)[0], a[1])
+    # without a clutter map every pixel is multiplied (a NaN feature where no pose is must reach the sums)
+    fm_nan = fm.clone()
+    ys, xs = torch.nonzero(uncovered, as_tuple=True)
+    fm_nan[1, 5, ys[0], xs[0]] = float("nan")
+    loss = ops.grid_score(None, fm_nan, None, packed=packed)[0]
+    assert bool(torch.isnan(loss[1]).all()) and not bool(torch.isnan(loss[0]).any()) and not bool(torch.isnan(loss[2]).any())
+    loss_c = ops.clutter_and_grid_score(fm_nan, clutter, packed)[1]
+    assert bool(torch.isnan(loss_c[1]).all()) and not bool(torch.isnan(loss_c[0]).any())
+
+
 def test_largest_maps_and_size_limits(gpu):
     """Largest maps.  The bit-exact renderer keeps 64-bit keys and a pair queue in LDS: with the 1118-vertex mesh
     it takes up to about 11 k pixels (96 x 112 here); the optimisation loop (32-bit keys) takes 128 x 128 = a
