@@ -487,7 +487,7 @@ __device__ inline void raster_pass1(const RasterCtx& rc, const Lds& s) {
             fv = face_verts(s, i0, i1, i2);
             const float zmax = fmaxf(fmaxf(fv.z0, fv.z1), fv.z2);
             const float farea = edge_fn(fv.x0, fv.y0, fv.x1, fv.y1, fv.x2, fv.y2);
-            ok = !(zmax < kEps) && !(farea <= kEps && farea >= -kEps) && (farea == farea);
+            ok = !(zmax < 0.0f) && !(farea <= kEps && farea >= -kEps) && (farea == farea);
             const float xmin = fminf(fminf(fv.x0, fv.x1), fv.x2), xmax = fmaxf(fmaxf(fv.x0, fv.x1), fv.x2);
             const float ymin = fminf(fminf(fv.y0, fv.y1), fv.y2), ymax = fmaxf(fmaxf(fv.y0, fv.y1), fv.y2);
             // conservative pixel range (flipped indices); 1e-3 pixel of slack, the exact test is in pass 2
@@ -626,7 +626,7 @@ __device__ inline bool walk_setup(const WalkGrid& g, int f, bool valid, bool cul
     const float A1 = fv.y0 - fv.y2, B1 = fv.x2 - fv.x0;
     const float A2 = fv.y1 - fv.y0, B2 = fv.x0 - fv.x1;
     const float farea = A0 * (fv.x0 - fv.x1) + B0 * (fv.y0 - fv.y1);
-    bool ok = valid && !(zmax < kEps) && (fabsf(farea) > kEps);            // false for NaN
+    bool ok = valid && !(zmax < 0.0f) && (fabsf(farea) > kEps);           // false for NaN
     // An outward-wound face seen from outside the solid looks at the camera when its signed area is positive.
     ok = ok && (!cull || farea > 0.0f);
     const float sgn = farea < 0.0f ? -1.0f : 1.0f;                          // edge functions oriented: inside means all positive

@@ -342,7 +342,7 @@ def rasterize_naive(xn, yn, zv, faces, H, W, rows_per_chunk=8):
         ymin, ymax = torch.minimum(torch.minimum(y0, y1), y2), torch.maximum(torch.maximum(y0, y1), y2)
         zmax = torch.maximum(torch.maximum(z0, z1), z2)
         farea = _edge(x0, y0, x1, y1, x2, y2)
-        face_ok = ~((zmax < KEPS) | ((farea <= KEPS) & (farea >= -KEPS)))
+        face_ok = ~((zmax < 0) | ((farea <= KEPS) & (farea >= -KEPS)))     # behind the camera (rasterize_meshes.cu: zmax < 0) / zero area
         for r0 in range(0, H, rows_per_chunk):
             r1 = min(H, r0 + rows_per_chunk)
             px = xf[None, :, None].expand(r1 - r0, -1, 1)
